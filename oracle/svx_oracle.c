@@ -1,0 +1,450 @@
+/*
+ * svx_oracle.c -- CPU restatement of the reference's census stereo-matching
+ * hot path.  TEST INFRASTRUCTURE ONLY: this file is the checker that the HIP
+ * kernels are compared against (tests/, __graft_entry__.smoke(), and the
+ * cpu_baseline leg of bench.py).  Nothing in the product path links, loads or
+ * calls it.
+ *
+ * Every function restates one reference routine in plain scalar C and cites
+ * the reference file:line it follows (paths relative to the reference root).
+ * Nothing here is copied from the reference: the SSE / OpenCV formulations
+ * are re-expressed as scalar loops over flat row-major buffers.
+ *
+ * Parity pinning: the reference cannot be built in this container (every hot
+ * translation unit includes OpenCV 2.4 / Boost headers that are absent), so
+ * the oracle is pinned against the known-answer values that were captured
+ * from the reference at survey time (tests/golden/survey_kat.json) and, for
+ * the popcount primitive, against the reference's own hammingdistance.cpp
+ * compiled from where it lies (oracle/_ref).
+ *
+ * Memory model shared by all functions ("flat guard" semantics): images are
+ * contiguous row-major with step == cols.  The reference does pointer
+ * arithmetic that leaves the row (wrapping into the neighbouring row of the
+ * same contiguous buffer) and, at four corner pixels, the buffer itself.  A
+ * read at a flat index outside [0, rows*cols) is DEFINED here to return 0,
+ * which is what the reference returns when its buffers sit between zeroed
+ * guard bands.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- helpers */
+
+static inline int8_t rd_s8(const int8_t *img, long n, long idx) {
+    return (idx >= 0 && idx < n) ? img[idx] : (int8_t)0;
+}
+static inline uint32_t rd_u32(const uint32_t *img, long n, long idx) {
+    return (idx >= 0 && idx < n) ? img[idx] : 0u;
+}
+
+/* FNV-1a 64 over a byte range (offset 1469598103934665603, prime 1099511628211). */
+ORC_API uint64_t orc_fnv1a64(const void *data, size_t nbytes, uint64_t h) {
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < nbytes; ++i) { h ^= p[i]; h *= 1099511628211ULL; }
+    return h;
+}
+ORC_API uint64_t orc_fnv1a64_init(void) { return 1469598103934665603ULL; }
+
+/* ------------------------------------------------------------------ a1 --
+ * sparsestereo/imageconversion.cpp:63-78  ImageConversion::unsignedToSigned
+ * dst = src - 128 with 8-bit wrap-around, i.e. src ^ 0x80. */
+ORC_API void orc_u8_to_s8(const uint8_t *src, int8_t *dst, size_t n) {
+    for (size_t i = 0; i < n; ++i) dst[i] = (int8_t)(uint8_t)(src[i] - 128u);
+}
+
+/* ------------------------------------------------------------------ a3 --
+ * sparsestereo/hammingdistance.h:18-46 (LUT) and :58-76 (parallel count).
+ * Restated as the classic mask-and-add reduction; equals hardware popcount. */
+ORC_API unsigned orc_popcount32(uint32_t v) {
+    v = (v & 0x55555555u) + ((v >> 1) & 0x55555555u);
+    v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+    v = (v & 0x0f0f0f0fu) + ((v >> 4) & 0x0f0f0f0fu);
+    v = (v & 0x00ff00ffu) + ((v >> 8) & 0x00ff00ffu);
+    return (v & 0xffffu) + (v >> 16);
+}
+ORC_API unsigned orc_hamming32(uint32_t a, uint32_t b) { return orc_popcount32(a ^ b); }
+
+/* ------------------------------------------------------------------ a2 --
+ * sparsestereo/census.cpp:17-94  Census::transform5x5SSE (+ :96-108 store).
+ * 24-bit layout.  For rows y in [2, rows-2) and ALL x in [0, cols):
+ *   neighbour (dy,dx), idx=(dy+2)*5+(dx+2), g=24-idx, bit = g<12 ? g : g-1,
+ *   bit set when centre > neighbour (signed 8-bit compare).
+ * The neighbour is fetched at flat index (y+dy)*cols + (x+dx): columns 0,1 and
+ * cols-2,cols-1 therefore see bytes of the adjacent row (census.cpp:28,41).
+ * Rows 0,1,rows-2,rows-1 of `out` are never written (census.cpp:22). */
+ORC_API void orc_census5x5_sse24(const int8_t *in, uint32_t *out, int rows, int cols) {
+    const long n = (long)rows * cols;
+    for (int y = 2; y < rows - 2; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const int8_t c = in[(long)y * cols + x];
+            uint32_t w = 0;
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dx = -2; dx <= 2; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    const int idx = (dy + 2) * 5 + (dx + 2);
+                    const int g = 24 - idx;
+                    const int bit = g < 12 ? g : g - 1;
+                    const int8_t nb = rd_s8(in, n, (long)(y + dy) * cols + (x + dx));
+                    if (c > nb) w |= 1u << bit;
+                }
+            out[(long)y * cols + x] = w;
+        }
+}
+
+/* ----------------------------------------------------------------- a2' --
+ * sparsestereo/census-inl.h:13-53  generic Census::transform5x5<T>.
+ * 25-bit layout bit = 24-idx (centre bit 12 always 0), interior pixels only
+ * (x in [2,cols-2), y in [2,rows-2)); everything else is left untouched. */
+ORC_API void orc_census5x5_generic25(const int8_t *in, uint32_t *out, int rows, int cols) {
+    for (int y = 2; y < rows - 2; ++y)
+        for (int x = 2; x < cols - 2; ++x) {
+            const int8_t c = in[(long)y * cols + x];
+            uint32_t w = 0;
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int idx = (dy + 2) * 5 + (dx + 2);
+                    if (c > in[(long)(y + dy) * cols + (x + dx)]) w |= 1u << (24 - idx);
+                }
+            out[(long)y * cols + x] = w;
+        }
+}
+
+/* ------------------------------------------------------------------ a4 --
+ * sparsestereo/censuswindow.h:96-107  CensusWindow<5>::match, popcount build.
+ * Three 64-bit loads per row starting at column x-2 => 5 rows x 6 columns
+ * (x-2 .. x+3).  Flat addressing: column x+3 may be the next row's first
+ * word.  Result is returned through `short` in the reference (max 720). */
+ORC_API int orc_window_cost_5x6(const uint32_t *ref, const uint32_t *cmp, int rows, int cols,
+                                int rx, int ry, int px, int py) {
+    const long n = (long)rows * cols;
+    int cost = 0;
+    for (int dy = -2; dy <= 2; ++dy)
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t a = rd_u32(ref, n, (long)(ry + dy) * cols + (rx - 2 + k));
+            const uint32_t b = rd_u32(cmp, n, (long)(py + dy) * cols + (px - 2 + k));
+            cost += (int)orc_popcount32(a ^ b);
+        }
+    return (int)(short)cost;
+}
+
+/* ----------------------------------------------------------------- a4' --
+ * sparsestereo/censuswindow.h:108-113 (and the LUT/SSE forms :119-232): the
+ * exact 5x5 window.  Not the behaviour of the reference as it compiles on
+ * x86-64 (that is a4); offered as an option. */
+ORC_API int orc_window_cost_5x5(const uint32_t *ref, const uint32_t *cmp, int rows, int cols,
+                                int rx, int ry, int px, int py) {
+    const long n = (long)rows * cols;
+    int cost = 0;
+    for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) {
+            const uint32_t a = rd_u32(ref, n, (long)(ry + dy) * cols + (rx + dx));
+            const uint32_t b = rd_u32(cmp, n, (long)(py + dy) * cols + (px + dx));
+            cost += (int)orc_popcount32(a ^ b);
+        }
+    return (int)(short)cost;
+}
+
+/* ------------------------------------------------------------------ a8 --
+ * denseCensusStereo/denseCensusStereo.cpp:87-131 (epipolarMatching, 5x5) and
+ * the driver loop :257-266.  For every pixel 2<=x<cols-2, 2<=y<rows-2 scan
+ * x_r = x, x-1, ... while x_r >= 5 and x_r > x-maxDisp; cost = sum over the
+ * 5x5 neighbourhood of per-pixel Hamming distances; strict '<' keeps the
+ * first minimum => smallest disparity on ties.  disparity = float(x - argmin);
+ * x < 5 never enters the loop => 0.  Pixels outside the loop bounds are not
+ * written. */
+ORC_API void orc_dense_wta5x5(const uint32_t *cl, const uint32_t *cr, int rows, int cols,
+                              int maxDisp, float *disp) {
+    for (int y = 2; y < rows - 2; ++y)
+        for (int x = 2; x < cols - 2; ++x) {
+            int minCost = INT_MAX, matchingX = x;
+            for (int i = x; i >= 5 && i > x - maxDisp; --i) {
+                int cost = 0;
+                for (int m = -2; m <= 2; ++m) {
+                    const uint32_t *l = cl + (long)(y + m) * cols;
+                    const uint32_t *r = cr + (long)(y + m) * cols;
+                    for (int n = -2; n <= 2; ++n) cost += (int)orc_popcount32(l[x + n] ^ r[i + n]);
+                }
+                if (cost < minCost) { minCost = cost; matchingX = i; }
+            }
+            disp[(long)y * cols + x] = (float)(x - matchingX);
+        }
+}
+
+/* Row-range variant used to time a bounded sample of a8 on the host and to
+ * split the work over threads; identical arithmetic. */
+ORC_API void orc_dense_wta5x5_rows(const uint32_t *cl, const uint32_t *cr, int rows, int cols,
+                                   int maxDisp, float *disp, int y0, int y1) {
+    if (y0 < 2) y0 = 2;
+    if (y1 > rows - 2) y1 = rows - 2;
+    for (int y = y0; y < y1; ++y)
+        for (int x = 2; x < cols - 2; ++x) {
+            int minCost = INT_MAX, matchingX = x;
+            for (int i = x; i >= 5 && i > x - maxDisp; --i) {
+                int cost = 0;
+                for (int m = -2; m <= 2; ++m) {
+                    const uint32_t *l = cl + (long)(y + m) * cols;
+                    const uint32_t *r = cr + (long)(y + m) * cols;
+                    for (int n = -2; n <= 2; ++n)
+                        cost += __builtin_popcount(l[x + n] ^ r[i + n]);
+                }
+                if (cost < minCost) { minCost = cost; matchingX = i; }
+            }
+            disp[(long)y * cols + x] = (float)(x - matchingX);
+        }
+}
+
+/* ------------------------------------------------------------------ a9 --
+ * highPerfStereo/highPerfStereoLib.cpp:88-139  epipolarMatching (A x A).
+ * half = costAggrWindowSize/2, margin = censusSize/2.  Scan x_r = x downwards
+ * while x_r >= half+margin and x_r > x-maxDisp.  Rows are clipped by
+ * y+m < rows (loop end) and y+m < 0 (skip); columns only by x_r+n < cols
+ * (loop end), so the LEFT index x+n is unclipped and addressed flat.  The
+ * returned cost is the single-pixel Hamming distance at the winner (:136),
+ * converted to `char`. */
+ORC_API void orc_epipolar_match(const uint32_t *cl, const uint32_t *cr, int rows, int cols,
+                                int censusSize, int costAggrWindowSize, int x, int y,
+                                int maxDisp, float *out_disp, int8_t *out_cost) {
+    const long n = (long)rows * cols;
+    const int half = costAggrWindowSize / 2, margin = censusSize / 2;
+    int minCost = INT_MAX, matchingX = x;
+    for (int i = x; i >= half + margin && i > x - maxDisp; --i) {
+        int cost = 0;
+        for (int m = -half; m <= half && y + m < rows; ++m) {
+            if (y + m < 0) continue;
+            const long rowoff = (long)(y + m) * cols;
+            for (int k = -half; k <= half && i + k < cols; ++k)
+                cost += (int)orc_popcount32(rd_u32(cl, n, rowoff + x + k) ^ rd_u32(cr, n, rowoff + i + k));
+        }
+        if (cost < minCost) { minCost = cost; matchingX = i; }
+    }
+    *out_disp = (float)(x - matchingX);
+    *out_cost = (int8_t)orc_popcount32(rd_u32(cl, n, (long)y * cols + x) ^ rd_u32(cr, n, (long)y * cols + matchingX));
+}
+
+/* ----------------------------------------------------------------- a10 --
+ * highPerfStereo/highPerfStereoLib.cpp:20-41  costEvaluation.
+ * For each point (x,y): xR = x - (int)floor(double(d)+0.5); xR < 2 => skip
+ * (the caller's pre-fill survives); else cost = (char)hamming(cl(y,x),
+ * cr(y,xR)).  xR has no upper bound check: the right word is addressed flat. */
+ORC_API void orc_cost_eval(const uint32_t *cl, const uint32_t *cr, int rows, int cols,
+                           const int32_t *pts_xy, int npts, const float *disp, int8_t *costs) {
+    const long n = (long)rows * cols;
+    for (int p = 0; p < npts; ++p) {
+        const int x = pts_xy[2 * p], y = pts_xy[2 * p + 1];
+        const float d = disp[(long)y * cols + x];
+        const int xr = x - (int)floor((double)d + 0.5);
+        if (xr < 2) continue;
+        costs[(long)y * cols + x] =
+            (int8_t)orc_popcount32(cl[(long)y * cols + x] ^ rd_u32(cr, n, (long)y * cols + xr));
+    }
+}
+
+/* ----------------------------------------------------------------- a11 --
+ * highPerfStereo/highPerfStereoLib.cpp:44-86  disparityRefinement, with the
+ * grid container of highPerfStereoLib.h:114-151.
+ * grid is (rows/g + 1) x (cols/g + 1); every cell starts as
+ * conf=(0,0,0.0f,tLow), inv=(0,0,tHigh).  Points are visited in the given
+ * order; all compares are strict, so the first point wins ties.  The
+ * finalCosts compare reads the stored byte as UNSIGNED (Mat_::ptr() without a
+ * type yields uchar*, :70) while mc is a signed char.
+ * Grid outputs are struct-of-arrays, cell index = j*gridW + i. */
+ORC_API void orc_refine(const int32_t *pts_xy, int npts, const float *disp, const int8_t *costs,
+                        int rows, int cols, int tLow, int tHigh, unsigned occGridSize,
+                        float *finalDisp, int8_t *finalCosts,
+                        int32_t *conf_x, int32_t *conf_y, float *conf_d, int8_t *conf_c,
+                        int32_t *inv_x, int32_t *inv_y, int8_t *inv_c) {
+    const unsigned gh = (unsigned)(rows / occGridSize) + 1, gw = (unsigned)(cols / occGridSize) + 1;
+    for (unsigned c = 0; c < gh * gw; ++c) {
+        conf_x[c] = 0; conf_y[c] = 0; conf_d[c] = 0.0f; conf_c[c] = (int8_t)tLow;
+        inv_x[c] = 0; inv_y[c] = 0; inv_c[c] = (int8_t)tHigh;
+    }
+    const int8_t tl = (int8_t)tLow, th = (int8_t)tHigh;
+    for (int p = 0; p < npts; ++p) {
+        const int u = pts_xy[2 * p], v = pts_xy[2 * p + 1];
+        const long o = (long)v * cols + u;
+        const float d = disp[o];
+        const int8_t mc = costs[o];
+        const unsigned cell = (unsigned)(v / (int)occGridSize) * gw + (unsigned)(u / (int)occGridSize);
+        if ((int)mc < (int)(uint8_t)finalCosts[o]) { finalDisp[o] = d; finalCosts[o] = mc; }
+        if (mc < tl && mc < conf_c[cell]) { conf_x[cell] = u; conf_y[cell] = v; conf_d[cell] = d; conf_c[cell] = mc; }
+        if (mc > th && mc > inv_c[cell]) { inv_x[cell] = u; inv_y[cell] = v; inv_c[cell] = mc; }
+    }
+}
+
+/* ------------------------------------------------------------ a5 + a6 ---
+ * sparsestereo/sparsestereo-inl.h:37-81 (match), :83-140 (calcCosts),
+ * :142-174 (getRowOffsets), :176-227 (denseConsistencyCheck), with rect==NULL:
+ * sparserectification.cpp:37-45,61-69 (copy + sort by (y,x),
+ * sparserectification.h:35-38), :106-108 (identity epiline-start table stored
+ * as short) and the dummy Epiline of stereorectification.h:40-50.
+ *
+ * Inputs are the caller's keypoint coordinates (float x,y).  Outputs, one per
+ * LEFT feature in (y,x)-sorted order:
+ *   out_left[i]  original index of the i-th sorted left feature,
+ *   out_right[i] original index of the matched right feature, or -1,
+ *   out_cost[i]  window cost of the match.
+ * Ties in the sort (identical coordinates) are broken by original index.
+ * A fresh SparseStereo instance is modelled: features skipped by the `ly < 2`
+ * continue (:99-101) keep the value-initialised pair (0,0), i.e. they come out
+ * matched to sorted right feature 0 with cost 0, exactly as the reference
+ * would emit them. */
+typedef struct { float x, y; int idx; } orc_feat;
+static int feat_cmp(const void *a, const void *b) {
+    const orc_feat *p = (const orc_feat *)a, *q = (const orc_feat *)b;
+    if (p->y < q->y) return -1;
+    if (p->y > q->y) return 1;
+    if (p->x < q->x) return -1;
+    if (p->x > q->x) return 1;
+    return (p->idx > q->idx) - (p->idx < q->idx);
+}
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+ORC_API int orc_sparse_match(const uint32_t *cl, const uint32_t *cr, int rows, int cols,
+                             const float *left_xy, int nl, const float *right_xy, int nr,
+                             int maxDisparity, float yTolerance, float uniqueness, int leftRightStep,
+                             int32_t *out_left, int32_t *out_right, int16_t *out_cost) {
+    if (nl == 0 || nr == 0) return 0;            /* :44-45 */
+    orc_feat *L = (orc_feat *)malloc(sizeof(orc_feat) * (size_t)nl);
+    orc_feat *R = (orc_feat *)malloc(sizeof(orc_feat) * (size_t)nr);
+    unsigned *offsets = (unsigned *)malloc(sizeof(unsigned) * (size_t)rows);
+    int *mfirst = (int *)calloc((size_t)nl, sizeof(int));
+    short *msecond = (short *)calloc((size_t)nl, sizeof(short));
+    for (int i = 0; i < nl; ++i) { L[i].x = left_xy[2 * i]; L[i].y = left_xy[2 * i + 1]; L[i].idx = i; }
+    for (int i = 0; i < nr; ++i) { R[i].x = right_xy[2 * i]; R[i].y = right_xy[2 * i + 1]; R[i].idx = i; }
+    qsort(L, (size_t)nl, sizeof(orc_feat), feat_cmp);
+    qsort(R, (size_t)nr, sizeof(orc_feat), feat_cmp);
+
+    /* getRowOffsets :142-174 */
+    {
+        int lastRow = -1;
+        for (int i = 0; i < nr; ++i) {
+            const int y = (int)(R[i].y + 0.5);
+            if (y >= rows - 1) break;
+            else if (y < 0) continue;
+            if (y != lastRow) {
+                for (int j = lastRow + 1; j <= y; ++j) offsets[j] = (unsigned)i;
+                lastRow = y;
+            }
+        }
+        for (int i = lastRow + 1; i < rows; ++i) offsets[i] = (unsigned)nr;
+    }
+
+    /* calcCosts :83-140 */
+    for (int l = 0; l < nl; ++l) {
+        const int ly = (int)(L[l].y + 0.5);
+        if (ly < 2) continue;                                   /* :99-101 */
+        if (ly >= rows - 2 - 1) {                               /* :102-107 */
+            for (; l < nl; ++l) mfirst[l] = -1;
+            break;
+        }
+        const int rightStart = (int)offsets[clampi((int)(ly - yTolerance), 0, rows - 1)];
+        const int rightEnd = (int)offsets[clampi((int)(ly + yTolerance) + 2, 0, rows - 1)];
+        short minCost = SHRT_MAX;
+        int minRight = -1;
+        const int rx = (int)(L[l].x + 0.5), ry = (int)(L[l].y + 0.5);
+        for (int r = rightStart; r < rightEnd; ++r) {
+            if (R[r].x <= L[l].x && R[r].x >= L[l].x - maxDisparity &&
+                fabs(L[l].y - R[r].y) <= yTolerance && R[r].x >= 2 && R[r].x < cols - 2) {
+                const short c = (short)orc_window_cost_5x6(cl, cr, rows, cols, rx, ry,
+                                                           (int)(R[r].x + 0.5), (int)(R[r].y + 0.5));
+                if (c < minCost) { minCost = c; minRight = r; }
+            }
+        }
+        mfirst[l] = minRight;
+        msecond[l] = minCost;
+    }
+
+    /* denseConsistencyCheck :176-227 (reference image = RIGHT census) */
+    for (int l = 0; l < nl; ++l) {
+        const int ly = (int)(L[l].y + 0.5);
+        if (ly < 2) continue;
+        if (ly >= rows - 2 - 1) break;
+        const int r = mfirst[l];
+        const short minCost = msecond[l];
+        if (r == -1) continue;
+        /* identity table lookup precompEpilinesStart(int(pt.y), clamp(int(rx+.5),0,cols)) :203-204;
+         * column == cols addresses the next row's column 0, whose entry is 0. */
+        int col = clampi((int)(R[r].x + 0.5), 0, cols);
+        const float leftStartX = (float)(short)(col == cols ? 0 : col);
+        const int startX = 2 > (int)leftStartX ? 2 : (int)leftStartX;
+        const int endLim = (int)(leftStartX + maxDisparity);
+        const int endX = cols - 2 < endLim ? cols - 2 : endLim;
+        const int y = (int)(L[l].y + 0.5);                      /* dummy epiline: at(x) = pt.y */
+        const int rpx = (int)(R[r].x + 0.5), rpy = (int)(R[r].y + 0.5);
+        const int lxi = (int)(L[l].x + 0.5);
+        for (int x = startX; x < endX; x += leftRightStep) {
+            if (y < 2 || y >= rows - 2) continue;
+            const short c = (short)orc_window_cost_5x6(cr, cl, rows, cols, rpx, rpy, x, y);
+            if ((float)c < (float)minCost / uniqueness && fabs((double)(x - lxi)) > leftRightStep) {
+                mfirst[l] = -1;
+                break;
+            }
+        }
+    }
+
+    for (int l = 0; l < nl; ++l) {
+        out_left[l] = L[l].idx;
+        out_right[l] = mfirst[l] == -1 ? -1 : R[mfirst[l]].idx;
+        out_cost[l] = mfirst[l] == -1 ? 0 : msecond[l];
+    }
+    free(L); free(R); free(offsets); free(mfirst); free(msecond);
+    return nl;
+}
+
+/* ----------------------------------------------------------------- a12 --
+ * Plane fit: plane/Plane.cpp:27-65 with linear-system-solving/
+ * CramerTheorem.cpp:24-48 -- solve [x y 1][a b c]^T = d for three vertices by
+ * Cramer's rule in double, results narrowed to float (Plane.h members are
+ * float).  A singular system leaves the plane at (0,0,0) (Plane.cpp:15-19,
+ * :48-53).  The cofactor expansion order follows Matrix::determinant
+ * (linear-system-solving/Matrix.cpp:38-54): first-row expansion. */
+static double det3(const double m[3][3]) {
+    return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1])
+         - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+         + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+ORC_API void orc_plane_fit(const double xy_d[9], float abc[3]) {
+    double A[3][3], M[3][3];
+    for (int i = 0; i < 3; ++i) { A[i][0] = xy_d[3 * i]; A[i][1] = xy_d[3 * i + 1]; A[i][2] = 1.0; }
+    const double dA = det3(A);
+    abc[0] = abc[1] = abc[2] = 0.0f;
+    if (dA == 0.0) return;
+    for (int k = 0; k < 3; ++k) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M[i][j] = (j == k) ? xy_d[3 * i + 2] : A[i][j];
+        abc[k] = (float)(det3(M) / dA);
+    }
+}
+
+/* Prior interpolation: highPerfStereo/highPerfStereoLib.cpp:532-554 with
+ * Plane::getDepth(Point2) plane/Plane.cpp:71-73:
+ *   prior(j,i) = float( double(a)*double(i) + double(b)*double(j) + double(c) )
+ * (float members promoted against Point2's double coordinates).  The
+ * reference asks Fade2D which triangle holds the pixel; that library is not
+ * available, so the point-in-triangle rule is build-defined ("parity
+ * unpinned" for pixels lying exactly on shared edges): a pixel belongs to the
+ * FIRST triangle in list order whose closed area contains it (three edge
+ * functions all >= 0 or all <= 0, evaluated in exact 64-bit integers).
+ * Pixels covered by no triangle keep their previous value. */
+ORC_API void orc_plane_prior_raster(const int32_t *tri_xy /* ntri*6 */, const float *tri_abc /* ntri*3 */,
+                                    int ntri, int rows, int cols, float *prior) {
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x)
+            for (int t = 0; t < ntri; ++t) {
+                const int32_t *v = tri_xy + 6 * t;
+                const int64_t e0 = (int64_t)(v[2] - v[0]) * (y - v[1]) - (int64_t)(v[3] - v[1]) * (x - v[0]);
+                const int64_t e1 = (int64_t)(v[4] - v[2]) * (y - v[3]) - (int64_t)(v[5] - v[3]) * (x - v[2]);
+                const int64_t e2 = (int64_t)(v[0] - v[4]) * (y - v[5]) - (int64_t)(v[1] - v[5]) * (x - v[4]);
+                if ((e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0)) {
+                    const float *p = tri_abc + 3 * t;
+                    prior[(long)y * cols + x] = (float)((double)p[0] * (double)x + (double)p[1] * (double)y + (double)p[2]);
+                    break;
+                }
+            }
+}

@@ -1,0 +1,159 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU checker.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+
+
+def _load():
+    so = os.path.join(_ORACLE_DIR, "liboracle.so")
+    src = os.path.join(_ORACLE_DIR, "svx_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return C.CDLL(so)
+
+
+lib = _load()
+_p = C.c_void_p
+lib.orc_fnv1a64.restype = C.c_uint64
+lib.orc_fnv1a64.argtypes = [_p, C.c_size_t, C.c_uint64]
+lib.orc_fnv1a64_init.restype = C.c_uint64
+lib.orc_popcount32.restype = C.c_uint
+lib.orc_popcount32.argtypes = [C.c_uint32]
+lib.orc_hamming32.restype = C.c_uint
+lib.orc_hamming32.argtypes = [C.c_uint32, C.c_uint32]
+lib.orc_u8_to_s8.argtypes = [_p, _p, C.c_size_t]
+lib.orc_census5x5_sse24.argtypes = [_p, _p, C.c_int, C.c_int]
+lib.orc_census5x5_generic25.argtypes = [_p, _p, C.c_int, C.c_int]
+for _n in ("orc_window_cost_5x6", "orc_window_cost_5x5"):
+    getattr(lib, _n).restype = C.c_int
+    getattr(lib, _n).argtypes = [_p, _p] + [C.c_int] * 6
+lib.orc_dense_wta5x5.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p]
+lib.orc_dense_wta5x5_rows.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int]
+lib.orc_epipolar_match.argtypes = [_p, _p] + [C.c_int] * 7 + [_p, _p]
+lib.orc_cost_eval.argtypes = [_p, _p, C.c_int, C.c_int, _p, C.c_int, _p, _p]
+lib.orc_refine.argtypes = [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint] + [_p] * 9
+lib.orc_sparse_match.restype = C.c_int
+lib.orc_sparse_match.argtypes = [_p, _p, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int,
+                                 C.c_int, C.c_float, C.c_float, C.c_int, _p, _p, _p]
+lib.orc_plane_fit.argtypes = [_p, _p]
+lib.orc_plane_prior_raster.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p]
+
+
+def _ptr(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fnv(a):
+    a = np.ascontiguousarray(a)
+    return "%016x" % lib.orc_fnv1a64(_ptr(a), a.nbytes, lib.orc_fnv1a64_init())
+
+
+def u8_to_s8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty(img.shape, dtype=np.int8)
+    lib.orc_u8_to_s8(_ptr(img), _ptr(out), img.size)
+    return out
+
+
+def census5x5(img_s8, layout="sse24", out=None):
+    img_s8 = np.ascontiguousarray(img_s8, dtype=np.int8)
+    rows, cols = img_s8.shape
+    if out is None:
+        out = np.zeros((rows, cols), dtype=np.uint32)
+    fn = lib.orc_census5x5_sse24 if layout == "sse24" else lib.orc_census5x5_generic25
+    fn(_ptr(img_s8), _ptr(out), rows, cols)
+    return out
+
+
+def window_cost(ref, cmp_, rx, ry, px, py, mode="5x6"):
+    rows, cols = ref.shape
+    fn = lib.orc_window_cost_5x6 if mode == "5x6" else lib.orc_window_cost_5x5
+    return fn(_ptr(ref), _ptr(cmp_), rows, cols, rx, ry, px, py)
+
+
+def dense_wta5x5(cl, cr, max_disp, out=None):
+    rows, cols = cl.shape
+    if out is None:
+        out = np.zeros((rows, cols), dtype=np.float32)
+    lib.orc_dense_wta5x5(_ptr(cl), _ptr(cr), rows, cols, max_disp, _ptr(out))
+    return out
+
+
+def epipolar_match(cl, cr, census_size, aggr, x, y, max_disp):
+    rows, cols = cl.shape
+    d = C.c_float()
+    c = C.c_int8()
+    lib.orc_epipolar_match(_ptr(cl), _ptr(cr), rows, cols, census_size, aggr, x, y, max_disp,
+                           C.byref(d), C.byref(c))
+    return d.value, c.value
+
+
+def cost_eval(cl, cr, pts_xy, disp, costs):
+    rows, cols = cl.shape
+    pts_xy = np.ascontiguousarray(pts_xy, dtype=np.int32)
+    lib.orc_cost_eval(_ptr(cl), _ptr(cr), rows, cols, _ptr(pts_xy), len(pts_xy), _ptr(disp), _ptr(costs))
+    return costs
+
+
+def refine(pts_xy, disp, costs, t_low, t_high, grid, final_disp, final_costs):
+    rows, cols = disp.shape
+    pts_xy = np.ascontiguousarray(pts_xy, dtype=np.int32)
+    gh, gw = rows // grid + 1, cols // grid + 1
+    g = dict(conf_x=np.zeros(gh * gw, np.int32), conf_y=np.zeros(gh * gw, np.int32),
+             conf_d=np.zeros(gh * gw, np.float32), conf_c=np.zeros(gh * gw, np.int8),
+             inv_x=np.zeros(gh * gw, np.int32), inv_y=np.zeros(gh * gw, np.int32),
+             inv_c=np.zeros(gh * gw, np.int8))
+    lib.orc_refine(_ptr(pts_xy), len(pts_xy), _ptr(disp), _ptr(costs), rows, cols, t_low, t_high, grid,
+                   _ptr(final_disp), _ptr(final_costs), _ptr(g["conf_x"]), _ptr(g["conf_y"]),
+                   _ptr(g["conf_d"]), _ptr(g["conf_c"]), _ptr(g["inv_x"]), _ptr(g["inv_y"]), _ptr(g["inv_c"]))
+    g["gw"], g["gh"] = gw, gh
+    return g
+
+
+def sparse_match(cl, cr, left_xy, right_xy, max_disp, y_tol=1.0, uniqueness=0.6, lr_step=1):
+    rows, cols = cl.shape
+    left_xy = np.ascontiguousarray(left_xy, dtype=np.float32).reshape(-1, 2)
+    right_xy = np.ascontiguousarray(right_xy, dtype=np.float32).reshape(-1, 2)
+    nl, nr = len(left_xy), len(right_xy)
+    ol = np.zeros(max(nl, 1), np.int32)
+    orr = np.zeros(max(nl, 1), np.int32)
+    oc = np.zeros(max(nl, 1), np.int16)
+    n = lib.orc_sparse_match(_ptr(cl), _ptr(cr), rows, cols, _ptr(left_xy), nl, _ptr(right_xy), nr,
+                             max_disp, y_tol, uniqueness, lr_step, _ptr(ol), _ptr(orr), _ptr(oc))
+    return ol[:n], orr[:n], oc[:n]
+
+
+def plane_fit(xyd):
+    xyd = np.ascontiguousarray(xyd, dtype=np.float64).reshape(9)
+    out = np.zeros(3, np.float32)
+    lib.orc_plane_fit(_ptr(xyd), _ptr(out))
+    return out
+
+
+def plane_prior_raster(tri_xy, tri_abc, rows, cols, prior):
+    tri_xy = np.ascontiguousarray(tri_xy, dtype=np.int32).reshape(-1, 6)
+    tri_abc = np.ascontiguousarray(tri_abc, dtype=np.float32).reshape(-1, 3)
+    lib.orc_plane_prior_raster(_ptr(tri_xy), _ptr(tri_abc), len(tri_xy), rows, cols, _ptr(prior))
+    return prior
+
+
+# ---- the formula image of tests/golden/survey_kat.json ----
+def kat_images():
+    R, Cc = 32, 64
+
+    def pix(y, x):
+        return (y * 37 + x * 101 + ((x * y) % 7) * 13 + ((x * x + 3 * y) % 11) * 29) & 255
+
+    right = np.zeros((R, Cc), np.uint8)
+    left = np.zeros((R, Cc), np.uint8)
+    for y in range(R):
+        d = 3 + y // 8
+        for x in range(Cc):
+            right[y, x] = pix(y, x)
+            left[y, x] = pix(y, x - d) if x >= d else pix(y + 1, x + 50)
+    return left, right
