@@ -1,0 +1,168 @@
+/*
+ * svx.h -- C ABI of libsvx: the census stereo-matching hot path of
+ * TomEwbank/StereoVision as hand-written HIP kernels for AMD MI355X (gfx950).
+ *
+ * The reference has no FFI layer: its boundary is a set of C++ signatures over
+ * cv::Mat_.  Each entry point below names the reference routine it replaces
+ * (file:line relative to the reference root).  Conventions:
+ *
+ *   - every image is row-major and contiguous (step == cols), one frame after
+ *     another when n_frames > 1 (frame stride == rows*cols elements);
+ *   - pointers are DEVICE pointers unless the parameter name ends in _host;
+ *   - work is enqueued on the context's stream and is asynchronous with
+ *     respect to the host unless the entry point has _host parameters (those
+ *     return after their results are on the host);
+ *   - return value: SVX_OK (0) or a negative svx_status; svx_last_error()
+ *     holds a message for the most recent failure of that context;
+ *   - a context belongs to one device and one host thread at a time; distinct
+ *     contexts are independent.
+ *
+ * Out-of-image addressing: the reference leaves rows through pointer
+ * arithmetic (census borders, 6-column window, unclipped disparity).  libsvx
+ * defines such an access as a flat index into the contiguous frame; an index
+ * outside the frame reads 0.  This equals the reference whenever its buffers
+ * lie between zeroed guard bands.
+ */
+#ifndef SVX_H
+#define SVX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVX_VERSION 100
+
+typedef enum svx_status {
+    SVX_OK = 0,
+    SVX_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad enum */
+    SVX_ERR_SIZE_MISMATCH = -2, /* "Mismatching image sizes" (sparsestereo-inl.h:42-43) */
+    SVX_ERR_EMPTY = -3,         /* "Input images are empty!" (highPerfStereoLib.cpp:184-185) */
+    SVX_ERR_HIP = -4,           /* a HIP runtime call or kernel launch failed */
+    SVX_ERR_NO_DEVICE = -5,     /* no usable gfx950 device */
+    SVX_ERR_UNSUPPORTED = -6,   /* parameter outside what the kernels were built for */
+    SVX_ERR_NOMEM = -7          /* device workspace allocation failed */
+} svx_status;
+
+typedef struct svx_ctx svx_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int svx_create(int device, svx_ctx **out);
+int svx_destroy(svx_ctx *ctx);
+/* hip_stream is a hipStream_t (NULL = the default stream). */
+int svx_set_stream(svx_ctx *ctx, void *hip_stream);
+int svx_synchronize(svx_ctx *ctx);
+int svx_version(void);
+const char *svx_strerror(int status);
+const char *svx_last_error(const svx_ctx *ctx);
+
+/* Device-memory helpers for bindings that cannot call HIP themselves. */
+int svx_malloc(svx_ctx *ctx, size_t bytes, void **dptr);
+int svx_free(svx_ctx *ctx, void *dptr);
+int svx_memset(svx_ctx *ctx, void *dptr, int value, size_t bytes);
+int svx_memcpy_h2d(svx_ctx *ctx, void *dst, const void *src_host, size_t bytes);
+int svx_memcpy_d2h(svx_ctx *ctx, void *dst_host, const void *src, size_t bytes);
+
+/* ---- a1: unsigned -> signed pixels -------------------------------------
+ * Replaces ImageConversion::unsignedToSigned, sparsestereo/imageconversion.h:24,
+ * imageconversion.cpp:63-78.  dst = src - 128 (mod 256). */
+int svx_u8_to_s8(svx_ctx *ctx, const uint8_t *src, int8_t *dst, int rows, int cols, int n_frames);
+
+/* ---- a2: 5x5 census transform ------------------------------------------
+ * Replaces Census::transform5x5, sparsestereo/census.h:17-18.
+ *   SVX_CENSUS_SSE24     the `char` specialisation, census.cpp:17-94: 24-bit
+ *                        words, rows [2,rows-2) x ALL columns written, border
+ *                        columns see the adjacent row (flat addressing).
+ *   SVX_CENSUS_GENERIC25 the generic template, census-inl.h:13-53: 25-bit
+ *                        words (centre bit 0), interior pixels only.
+ * Pixels the reference does not write are left untouched unless
+ * SVX_CENSUS_ZERO_REST is or-ed in, which writes 0 there.
+ * svx_census5x5_u8 fuses a1 and takes the unsigned image directly. */
+enum { SVX_CENSUS_SSE24 = 0, SVX_CENSUS_GENERIC25 = 1, SVX_CENSUS_ZERO_REST = 16 };
+int svx_census5x5_s8(svx_ctx *ctx, const int8_t *in, uint32_t *out, int rows, int cols, int n_frames, int flags);
+int svx_census5x5_u8(svx_ctx *ctx, const uint8_t *in, uint32_t *out, int rows, int cols, int n_frames, int flags);
+
+/* ---- a4: census window cost ---------------------------------------------
+ * Replaces CensusWindow<5>::setReferencePoint + match, sparsestereo/
+ * censuswindow.h:46-49, :96-107.  For pair p: cost[p] = window Hamming cost of
+ * ref at (ref_xy[2p], ref_xy[2p+1]) against cmp at (cmp_xy[2p], cmp_xy[2p+1]).
+ *   SVX_WINDOW_5X6  what the reference computes on x86-64 (5 rows x columns
+ *                   x-2..x+3);  SVX_WINDOW_5X5  the exact 5x5 window. */
+enum { SVX_WINDOW_5X6 = 0, SVX_WINDOW_5X5 = 1 };
+int svx_census_window_cost(svx_ctx *ctx, const uint32_t *ref, const uint32_t *cmp, int rows, int cols,
+                           const int32_t *ref_xy, const int32_t *cmp_xy, int n_pairs, int16_t *cost, int mode);
+
+/* ---- a5 + a6 + a7: sparse feature matching ------------------------------
+ * Replaces SparseStereo<CensusWindow<5>,short>::match, sparsestereo/
+ * sparsestereo.h:24-30, sparsestereo-inl.h:37-227, for rect == NULL (inputs
+ * already rectified).  Keypoints are float (x,y) pairs on the HOST; results
+ * come back on the host, one record per left feature in (y,x)-sorted order:
+ * out_left = index into left_xy, out_right = index into right_xy or -1
+ * (rejected / unmatched), out_cost = 5x6 window cost.  *n_out = number of
+ * records (0 when either list is empty, sparsestereo-inl.h:44-45). */
+int svx_sparse_match(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                     const float *left_xy_host, int n_left, const float *right_xy_host, int n_right,
+                     int max_disparity, float y_tolerance, float uniqueness, int left_right_step,
+                     int32_t *out_left_host, int32_t *out_right_host, int16_t *out_cost_host, int *n_out);
+
+/* ---- a8: dense winner-takes-all ------------------------------------------
+ * Replaces epipolarMatching + the driver loop of denseCensusStereo/
+ * denseCensusStereo.cpp:87-131, :257-266: 5x5-aggregated Hamming cost, every
+ * disparity d in [0, min(max_disp-1, x-5)], strict '<' (ties -> smallest d).
+ * svx_dense_wta5x5 writes pixels 2<=x<cols-2, 2<=y<rows-2 only (as the
+ * reference does).  svx_dense_census_wta_u8 is the fused hot path: a1 + a2 on
+ * both images and a8, no census image or cost volume in HBM; it writes the
+ * whole frame (0 outside the interior, the reference's initial value). */
+int svx_dense_wta5x5(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right,
+                     int rows, int cols, int n_frames, int max_disp, float *disparity);
+int svx_dense_census_wta_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right,
+                            int rows, int cols, int n_frames, int max_disp, float *disparity);
+
+/* ---- a9: batched full-range epipolar search ------------------------------
+ * Replaces epipolarMatching, highPerfStereo/highPerfStereoLib.h:211-214,
+ * highPerfStereoLib.cpp:88-139, for n points at once.  out_cost is the
+ * single-pixel Hamming distance at the winner (:136). */
+int svx_epipolar_match_batch(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right,
+                             int rows, int cols, int census_size, int cost_aggr_window_size,
+                             const int32_t *pts_xy, int n_pts, int max_disp, float *out_disp, int8_t *out_cost);
+
+/* ---- a10: cost of the plane prior ----------------------------------------
+ * Replaces costEvaluation, highPerfStereoLib.h:196-200, .cpp:20-41.
+ * costs is in/out (the caller pre-fills it with tHigh, .cpp:573). */
+int svx_cost_eval(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                  const int32_t *pts_xy, int n_pts, const float *disparities, int8_t *costs);
+
+/* ---- a11: accept / refine + occupancy grid --------------------------------
+ * Replaces disparityRefinement, highPerfStereoLib.h:203-209, .cpp:44-86, and
+ * the PotentialSupports container, highPerfStereoLib.h:114-151, returned as
+ * struct-of-arrays with cell index j*grid_w + i, grid_w = cols/g + 1,
+ * grid_h = rows/g + 1.  pts_xy must be in the caller's visiting order (raster
+ * order in the reference): ties go to the earliest point. */
+int svx_refine(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float *disparities, const int8_t *costs,
+               int rows, int cols, int t_low, int t_high, unsigned occ_grid_size,
+               float *final_disparities, int8_t *final_costs,
+               int32_t *conf_x, int32_t *conf_y, float *conf_d, int8_t *conf_c,
+               int32_t *inv_x, int32_t *inv_y, int8_t *inv_c);
+
+/* ---- a12: plane prior ------------------------------------------------------
+ * svx_plane_fit replaces Plane::Plane(Triangle2*, Mat_<float>), plane/
+ * Plane.cpp:27-65 (Cramer's rule in double, CramerTheorem.cpp:24-48): for
+ * triangle t with integer vertices tri_xy[6t..6t+5] it reads the three vertex
+ * disparities from `disparities` and writes float a,b,c to tri_abc[3t..].
+ * svx_plane_prior_raster replaces the interpolation loop highPerfStereoLib.cpp:
+ * 532-554 with Plane::getDepth, Plane.cpp:71-73: every pixel inside a
+ * triangle gets float(a*x + b*y + c) evaluated in double; pixels outside all
+ * triangles keep their value.  A pixel on a shared edge takes the triangle
+ * that comes first in the list (the reference delegates this choice to
+ * Fade2D's locate()). */
+int svx_plane_fit(svx_ctx *ctx, const int32_t *tri_xy, int n_tri, const float *disparities, int rows, int cols,
+                  float *tri_abc);
+int svx_plane_prior_raster(svx_ctx *ctx, const int32_t *tri_xy, const float *tri_abc, int n_tri,
+                           int rows, int cols, float *prior);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVX_H */

@@ -429,8 +429,8 @@ ORC_API void orc_plane_fit(const double xy_d[9], float abc[3]) {
  * reference asks Fade2D which triangle holds the pixel; that library is not
  * available, so the point-in-triangle rule is build-defined ("parity
  * unpinned" for pixels lying exactly on shared edges): a pixel belongs to the
- * FIRST triangle in list order whose closed area contains it (three edge
- * functions all >= 0 or all <= 0, evaluated in exact 64-bit integers).
+ * FIRST non-degenerate triangle in list order whose closed area contains it
+ * (three edge functions all >= 0 or all <= 0, in exact 64-bit integers).
  * Pixels covered by no triangle keep their previous value. */
 ORC_API void orc_plane_prior_raster(const int32_t *tri_xy /* ntri*6 */, const float *tri_abc /* ntri*3 */,
                                     int ntri, int rows, int cols, float *prior) {
@@ -438,6 +438,8 @@ ORC_API void orc_plane_prior_raster(const int32_t *tri_xy /* ntri*6 */, const fl
         for (int x = 0; x < cols; ++x)
             for (int t = 0; t < ntri; ++t) {
                 const int32_t *v = tri_xy + 6 * t;
+                const int64_t area2 = (int64_t)(v[2] - v[0]) * (v[5] - v[1]) - (int64_t)(v[3] - v[1]) * (v[4] - v[0]);
+                if (area2 == 0) continue;   /* degenerate triangles own nothing */
                 const int64_t e0 = (int64_t)(v[2] - v[0]) * (y - v[1]) - (int64_t)(v[3] - v[1]) * (x - v[0]);
                 const int64_t e1 = (int64_t)(v[4] - v[2]) * (y - v[3]) - (int64_t)(v[5] - v[3]) * (x - v[2]);
                 const int64_t e2 = (int64_t)(v[0] - v[4]) * (y - v[5]) - (int64_t)(v[1] - v[5]) * (x - v[4]);

@@ -1,0 +1,22 @@
+"""stereovision_amd -- MI355X (gfx950) kernels for the census stereo-matching hot path of
+TomEwbank/StereoVision, behind the C ABI declared in include/svx.h.
+
+This package is a thin ctypes binding over ``libsvx.so`` (built in-tree from
+``stereovision_amd/csrc``).  There is no CPU fallback: importing works anywhere, but creating a
+:class:`Context` raises unless the library is present and a gfx950 device is visible.
+"""
+from ._lib import (  # noqa: F401
+    Context,
+    SvxError,
+    lib_path,
+    load_library,
+    CENSUS_SSE24,
+    CENSUS_GENERIC25,
+    CENSUS_ZERO_REST,
+    WINDOW_5X6,
+    WINDOW_5X5,
+    EXPORTS,
+)
+
+__all__ = ["Context", "SvxError", "lib_path", "load_library", "CENSUS_SSE24", "CENSUS_GENERIC25",
+           "CENSUS_ZERO_REST", "WINDOW_5X6", "WINDOW_5X5", "EXPORTS"]

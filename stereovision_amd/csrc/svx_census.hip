@@ -1,0 +1,202 @@
+// a1 (unsigned -> signed pixels) and a2 (5x5 census transform) for gfx950.
+//
+// Both kernels are HBM-bound: a1 moves 1 B in + 1 B out per pixel, a2 1 B in +
+// 4 B out per pixel.  The census kernel stages a 256 x 16 pixel tile plus its
+// 2-pixel halo in LDS with 16-byte-coalesced row loads (the halo re-reads hit
+// L2) and every lane emits four consecutive descriptors as one 16-byte store.
+#include "svx_common.hpp"
+
+// ---------------------------------------------------------------- a1 -----
+__global__ __launch_bounds__(256) void u8_to_s8_vec_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long nvec) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        uint4 v = src[i];
+        v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+        dst[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void u8_to_s8_byte_kernel(const uint8_t *__restrict__ src, int8_t *__restrict__ dst, long first, long n) {
+    for (long i = first + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = (int8_t)(src[i] ^ 0x80u);
+}
+
+SVX_API int svx_u8_to_s8(svx_ctx *ctx, const uint8_t *src, int8_t *dst, int rows, int cols, int n_frames) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, src && dst, SVX_ERR_INVALID_ARG, "svx_u8_to_s8: null image pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "svx_u8_to_s8: empty image");
+    const long n = (long)rows * cols * n_frames;
+    long nvec = 0;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) nvec = n / 16;
+    if (nvec > 0) {
+        unsigned grid = svx_cdiv(nvec, 256);
+        if (grid > 2048) grid = 2048;
+        u8_to_s8_vec_kernel<<<grid, 256, 0, ctx->stream>>>((const uint4 *)src, (uint4 *)dst, nvec);
+        SVX_LAUNCH_CHECK(ctx, "u8_to_s8_vec_kernel");
+    }
+    if (nvec * 16 < n) {
+        unsigned grid = svx_cdiv(n - nvec * 16, 256);
+        if (grid > 2048) grid = 2048;
+        u8_to_s8_byte_kernel<<<grid, 256, 0, ctx->stream>>>(src, dst, nvec * 16, n);
+        SVX_LAUNCH_CHECK(ctx, "u8_to_s8_byte_kernel");
+    }
+    return SVX_OK;
+}
+
+// ---------------------------------------------------------------- a2 -----
+// Bit position of neighbour (dy,dx) in the 24-bit word: idx=(dy+2)*5+(dx+2),
+// g=24-idx, bit = g<12 ? g : g-1  (the centre, idx 12, has no bit).
+__host__ __device__ constexpr int census_bit24(int dy, int dx) {
+    return (24 - ((dy + 2) * 5 + (dx + 2))) < 12 ? (24 - ((dy + 2) * 5 + (dx + 2))) : (24 - ((dy + 2) * 5 + (dx + 2))) - 1;
+}
+// 24-bit word -> 25-bit word of the generic template (bit = 24-idx).
+__device__ __forceinline__ uint32_t census24_to_25(uint32_t w) { return (w & 0xFFFu) | ((w >> 12) << 13); }
+
+constexpr int CT_W = 256;            // tile width in pixels (one wave spans it: 64 lanes x 4 px)
+constexpr int CT_H = 16;             // tile height: 4 waves x 4 rows
+constexpr int CT_LROW = CT_W / 4 + 2;  // dwords per staged row: columns x0-4 .. x0+CT_W+3
+
+// Requires cols % 4 == 0 and 4-byte aligned frame bases, so that every staged
+// dword lies entirely inside or entirely outside the frame.
+template <bool IS_U8>
+__global__ __launch_bounds__(256) void census5x5_tile_kernel(const uint8_t *__restrict__ in_all, uint32_t *__restrict__ out_all,
+                                                             int rows, int cols, int flags) {
+    __shared__ uint32_t tile[(CT_H + 4) * CT_LROW];
+    const long n = (long)rows * cols;
+    const uint8_t *in = in_all + (long)blockIdx.z * n;
+    uint32_t *out = out_all + (long)blockIdx.z * n;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < (CT_H + 4) * CT_LROW; i += 256) {
+        const int r = i / CT_LROW, k = i - r * CT_LROW;
+        const long flat = (long)(y0 - 2 + r) * cols + (x0 - 4 + 4 * k);
+        uint32_t v = 0;
+        if (flat >= 0 && flat < n) {
+            v = *reinterpret_cast<const uint32_t *>(in + flat);
+            if (IS_U8) v ^= 0x80808080u;
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int x = x0 + lane * 4;
+    if (x >= cols) return;
+    const bool generic = (flags & 15) == SVX_CENSUS_GENERIC25;
+    const bool zero_rest = (flags & SVX_CENSUS_ZERO_REST) != 0;
+
+    // 64-bit window of row r covering columns x-2 .. x+5.
+    auto window = [&](int r) -> uint64_t {
+        const uint32_t *p = tile + r * CT_LROW + lane;
+        const uint32_t a = p[0], b = p[1], c = p[2];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, 2);
+        const uint32_t hi = __builtin_amdgcn_alignbyte(c, b, 2);
+        return ((uint64_t)hi << 32) | lo;
+    };
+
+    uint64_t w[5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r + 1] = window(wave * 4 + r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = y0 + wave * 4 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = w[r + 1];
+        w[4] = window(wave * 4 + j + 4);
+        if (y >= rows) break;
+        uint32_t res[4];
+        if (y >= 2 && y < rows - 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = (int8_t)(w[2] >> (8 * (2 + i)));
+                uint32_t word = 0;
+#pragma unroll
+                for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+                    for (int dx = -2; dx <= 2; ++dx) {
+                        if (dy == 0 && dx == 0) continue;
+                        const int nb = (int8_t)(w[dy + 2] >> (8 * (2 + i + dx)));
+                        word |= (uint32_t)(c > nb) << census_bit24(dy, dx);
+                    }
+                res[i] = generic ? census24_to_25(word) : word;
+            }
+            uint32_t *o = out + (long)y * cols + x;
+            if (!generic) {
+                *reinterpret_cast<uint4 *>(o) = make_uint4(res[0], res[1], res[2], res[3]);
+            } else if (x >= 2 && x + 3 < cols - 2) {
+                *reinterpret_cast<uint4 *>(o) = make_uint4(res[0], res[1], res[2], res[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool interior = (x + i >= 2) && (x + i < cols - 2);
+                    if (interior) o[i] = res[i];
+                    else if (zero_rest) o[i] = 0u;
+                }
+            }
+        } else if (zero_rest) {
+            *reinterpret_cast<uint4 *>(out + (long)y * cols + x) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
+// Any width / alignment: one thread per pixel straight from global memory.
+template <bool IS_U8>
+__global__ __launch_bounds__(256) void census5x5_pixel_kernel(const uint8_t *__restrict__ in_all, uint32_t *__restrict__ out_all,
+                                                              int rows, int cols, int flags) {
+    const long n = (long)rows * cols;
+    const uint8_t *in = in_all + (long)blockIdx.z * n;
+    uint32_t *out = out_all + (long)blockIdx.z * n;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const bool generic = (flags & 15) == SVX_CENSUS_GENERIC25;
+    const bool zero_rest = (flags & SVX_CENSUS_ZERO_REST) != 0;
+    const bool written = (y >= 2 && y < rows - 2) && (!generic || (x >= 2 && x < cols - 2));
+    if (!written) {
+        if (zero_rest) out[(long)y * cols + x] = 0u;
+        return;
+    }
+    auto px = [&](long flat) -> int {
+        if (flat < 0 || flat >= n) return 0;
+        return IS_U8 ? (int)(int8_t)(in[flat] ^ 0x80u) : (int)(int8_t)in[flat];
+    };
+    const int c = px((long)y * cols + x);
+    uint32_t word = 0;
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            if (dy == 0 && dx == 0) continue;
+            word |= (uint32_t)(c > px((long)(y + dy) * cols + (x + dx))) << census_bit24(dy, dx);
+        }
+    out[(long)y * cols + x] = generic ? census24_to_25(word) : word;
+}
+
+template <bool IS_U8>
+static int census_dispatch(svx_ctx *ctx, const void *in, uint32_t *out, int rows, int cols, int n_frames, int flags, const char *who) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, in && out, SVX_ERR_INVALID_ARG, "census5x5: null image pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "census5x5: empty image");
+    const int layout = flags & 15;
+    SVX_REQUIRE(ctx, layout == SVX_CENSUS_SSE24 || layout == SVX_CENSUS_GENERIC25, SVX_ERR_INVALID_ARG, "census5x5: unknown layout flag");
+    SVX_REQUIRE(ctx, (flags & ~(15 | SVX_CENSUS_ZERO_REST)) == 0, SVX_ERR_INVALID_ARG, "census5x5: unknown flag bits");
+    SVX_REQUIRE(ctx, n_frames <= 65535, SVX_ERR_UNSUPPORTED, "census5x5: more than 65535 frames per call");
+    const bool fast = (cols % 4 == 0) && (((uintptr_t)in & 3u) == 0) && (((uintptr_t)out & 15u) == 0);
+    if (fast) {
+        dim3 grid(svx_cdiv(cols, CT_W), svx_cdiv(rows, CT_H), n_frames);
+        census5x5_tile_kernel<IS_U8><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)in, out, rows, cols, flags);
+    } else {
+        dim3 grid(svx_cdiv(cols, 64), svx_cdiv(rows, 4), n_frames);
+        census5x5_pixel_kernel<IS_U8><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)in, out, rows, cols, flags);
+    }
+    SVX_LAUNCH_CHECK(ctx, who);
+    return SVX_OK;
+}
+
+SVX_API int svx_census5x5_s8(svx_ctx *ctx, const int8_t *in, uint32_t *out, int rows, int cols, int n_frames, int flags) {
+    return census_dispatch<false>(ctx, in, out, rows, cols, n_frames, flags, "census5x5 (s8)");
+}
+SVX_API int svx_census5x5_u8(svx_ctx *ctx, const uint8_t *in, uint32_t *out, int rows, int cols, int n_frames, int flags) {
+    return census_dispatch<true>(ctx, in, out, rows, cols, n_frames, flags, "census5x5 (u8)");
+}

@@ -1,0 +1,66 @@
+// Internal definitions shared by the libsvx translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/svx.h"
+
+struct svx_ctx {
+    int device;
+    hipStream_t stream;
+    void *ws;             // device workspace, grown on demand
+    size_t ws_bytes;
+    void *pinned;         // pinned host staging buffer, grown on demand
+    size_t pinned_bytes;
+    char err[256];
+};
+
+#define SVX_API extern "C" __attribute__((visibility("default")))
+
+inline int svx_fail(svx_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define SVX_HIP(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return svx_fail((ctx), SVX_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define SVX_LAUNCH_CHECK(ctx, name)                                                          \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess)                                                                \
+            return svx_fail((ctx), SVX_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+#define SVX_REQUIRE(ctx, cond, code, msg)                          \
+    do {                                                           \
+        if (!(cond)) return svx_fail((ctx), (code), "%s", (msg));  \
+    } while (0)
+
+// Makes the context's device current and returns its workspace grown to at least `bytes`.
+int svx_ws_reserve(svx_ctx *ctx, size_t bytes, void **out);
+int svx_pinned_reserve(svx_ctx *ctx, size_t bytes, void **out);
+int svx_enter(svx_ctx *ctx);
+
+// ---- device helpers -------------------------------------------------------
+
+// Flat-guard read: index into one contiguous frame of n elements, 0 outside.
+__device__ __forceinline__ uint32_t ld_guard_u32(const uint32_t *__restrict__ img, long n, long idx) {
+    return (idx >= 0 && idx < n) ? img[idx] : 0u;
+}
+
+__device__ __forceinline__ int popc32(uint32_t v) { return __builtin_popcount(v); }
+
+// Grid-stride friendly ceil-div.
+static inline unsigned svx_cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }

@@ -1,0 +1,312 @@
+// Plane-prior path for gfx950: a9 (batched full-range epipolar search),
+// a10 (cost of the prior), a11 (accept / refine + occupancy grid) and
+// a12 (plane fit + prior rasterisation).  All of it is gather-bound integer
+// work: one census word per side per evaluated pixel.
+#include "svx_common.hpp"
+
+// ---------------------------------------------------------------- a9 -----
+// One wavefront per query point; lanes take disparities d = lane, lane+64, ...
+// and evaluate the whole A x A aggregate; the winner is the minimum of
+// (cost << 32 | d), i.e. the smallest disparity among equal costs, which is
+// what a strict '<' scan from d = 0 upwards keeps.
+__global__ __launch_bounds__(256) void epipolar_match_kernel(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                                             int half, int margin, const int32_t *__restrict__ pts_xy, int n_pts, int max_disp,
+                                                             float *__restrict__ out_disp, int8_t *__restrict__ out_cost) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= n_pts) return;
+    const long n = (long)rows * cols;
+    const int x = pts_xy[2 * p], y = pts_xy[2 * p + 1];
+    unsigned long long best = ~0ull;
+    for (int d = lane; d < max_disp; d += 64) {
+        const int i = x - d;
+        if (i < half + margin) break;
+        unsigned cost = 0;
+        for (int m = -half; m <= half && y + m < rows; ++m) {
+            if (y + m < 0) continue;
+            const long ro = (long)(y + m) * cols;
+            for (int k = -half; k <= half && i + k < cols; ++k)
+                cost += popc32(ld_guard_u32(cl, n, ro + x + k) ^ ld_guard_u32(cr, n, ro + i + k));
+        }
+        const unsigned long long key = ((unsigned long long)cost << 32) | (unsigned)d;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = __shfl_xor(best, s, 64);
+        best = o < best ? o : best;
+    }
+    if (lane == 0) {
+        const int d = best == ~0ull ? 0 : (int)(unsigned)(best & 0xffffffffu);
+        out_disp[p] = (float)d;
+        out_cost[p] = (int8_t)popc32(ld_guard_u32(cl, n, (long)y * cols + x) ^ ld_guard_u32(cr, n, (long)y * cols + (x - d)));
+    }
+}
+
+SVX_API int svx_epipolar_match_batch(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right,
+                                     int rows, int cols, int census_size, int cost_aggr_window_size,
+                                     const int32_t *pts_xy, int n_pts, int max_disp, float *out_disp, int8_t *out_cost) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, census_left && census_right, SVX_ERR_INVALID_ARG, "svx_epipolar_match_batch: null census pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_epipolar_match_batch: empty image");
+    SVX_REQUIRE(ctx, census_size >= 1 && cost_aggr_window_size >= 1, SVX_ERR_INVALID_ARG, "svx_epipolar_match_batch: window sizes must be >= 1");
+    SVX_REQUIRE(ctx, n_pts >= 0, SVX_ERR_INVALID_ARG, "svx_epipolar_match_batch: negative point count");
+    if (n_pts == 0) return SVX_OK;
+    SVX_REQUIRE(ctx, pts_xy && out_disp && out_cost, SVX_ERR_INVALID_ARG, "svx_epipolar_match_batch: null point or output pointer");
+    epipolar_match_kernel<<<svx_cdiv(n_pts, 4), 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, cost_aggr_window_size / 2,
+                                                                      census_size / 2, pts_xy, n_pts, max_disp, out_disp, out_cost);
+    SVX_LAUNCH_CHECK(ctx, "epipolar_match_kernel");
+    return SVX_OK;
+}
+
+// --------------------------------------------------------------- a10 -----
+__global__ __launch_bounds__(256) void cost_eval_kernel(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                                        const int32_t *__restrict__ pts_xy, int n_pts, const float *__restrict__ disp,
+                                                        int8_t *__restrict__ costs) {
+    const long n = (long)rows * cols;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pts; p += gridDim.x * blockDim.x) {
+        const int2 pt = reinterpret_cast<const int2 *>(pts_xy)[p];
+        const int x = pt.x, y = pt.y;
+        if (x < 0 || x >= cols || y < 0 || y >= rows) continue;
+        const long o = (long)y * cols + x;
+        const int xr = x - (int)floor((double)disp[o] + 0.5);
+        if (xr < 2) continue;
+        costs[o] = (int8_t)popc32(cl[o] ^ ld_guard_u32(cr, n, (long)y * cols + xr));
+    }
+}
+
+SVX_API int svx_cost_eval(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                          const int32_t *pts_xy, int n_pts, const float *disparities, int8_t *costs) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, census_left && census_right && disparities && costs, SVX_ERR_INVALID_ARG, "svx_cost_eval: null image pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_cost_eval: empty image");
+    SVX_REQUIRE(ctx, n_pts >= 0, SVX_ERR_INVALID_ARG, "svx_cost_eval: negative point count");
+    if (n_pts == 0) return SVX_OK;
+    SVX_REQUIRE(ctx, pts_xy != nullptr, SVX_ERR_INVALID_ARG, "svx_cost_eval: null point list");
+    unsigned grid = svx_cdiv(n_pts, 256);
+    if (grid > 4096) grid = 4096;
+    cost_eval_kernel<<<grid, 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, pts_xy, n_pts, disparities, costs);
+    SVX_LAUNCH_CHECK(ctx, "cost_eval_kernel");
+    return SVX_OK;
+}
+
+// --------------------------------------------------------------- a11 -----
+// Per-point accept step plus per-cell winners.  A sequential scan with strict
+// compares keeps, per cell, the lowest cost below tLow (confident support) and
+// the highest cost above tHigh (invalid match), earliest point first; that is
+// the minimum of the keys below, found with one 64-bit atomic per wavefront
+// when the wavefront's points share a cell and one per lane otherwise.
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = __shfl_xor(v, s, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void refine_points_kernel(const int32_t *__restrict__ pts_xy, int n_pts, const float *__restrict__ disp,
+                                                            const int8_t *__restrict__ costs, int rows, int cols, int t_low, int t_high,
+                                                            int grid_size, int grid_w, float *__restrict__ final_disp, int8_t *__restrict__ final_costs,
+                                                            unsigned long long *__restrict__ conf_key, unsigned long long *__restrict__ inv_key) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ck = ~0ull, ik = ~0ull;
+    int cell = -1;
+    if (p < n_pts) {
+        const int2 pt = reinterpret_cast<const int2 *>(pts_xy)[p];
+        const int u = pt.x, v = pt.y;
+        if (u >= 0 && u < cols && v >= 0 && v < rows) {
+            const long o = (long)v * cols + u;
+            const float d = disp[o];
+            const int mc = costs[o];
+            if (mc < (int)(uint8_t)final_costs[o]) { final_disp[o] = d; final_costs[o] = (int8_t)mc; }
+            cell = (v / grid_size) * grid_w + (u / grid_size);
+            if (mc < t_low) ck = ((unsigned long long)(unsigned)(mc + 128) << 32) | (unsigned)p;
+            if (mc > t_high) ik = ((unsigned long long)(unsigned)(127 - mc) << 32) | (unsigned)p;
+        }
+    }
+    const int first = __builtin_amdgcn_readfirstlane(cell);
+    if (__all(cell == first || cell < 0)) {
+        // every valid lane of this wavefront is in one cell (or the first lane is invalid and all are)
+        const unsigned long long c = wave_min_u64(ck), i = wave_min_u64(ik);
+        int tgt = cell;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) tgt = max(tgt, __shfl_xor(tgt, s, 64));
+        if ((threadIdx.x & 63) == 0 && tgt >= 0) {
+            if (c != ~0ull) atomicMin(conf_key + tgt, c);
+            if (i != ~0ull) atomicMin(inv_key + tgt, i);
+        }
+    } else if (cell >= 0) {
+        if (ck != ~0ull) atomicMin(conf_key + cell, ck);
+        if (ik != ~0ull) atomicMin(inv_key + cell, ik);
+    }
+}
+
+__global__ __launch_bounds__(256) void refine_cells_kernel(const int32_t *__restrict__ pts_xy, const float *__restrict__ disp,
+                                                           const int8_t *__restrict__ costs, int cols, int t_low, int t_high, int n_cells,
+                                                           const unsigned long long *__restrict__ conf_key, const unsigned long long *__restrict__ inv_key,
+                                                           int32_t *conf_x, int32_t *conf_y, float *conf_d, int8_t *conf_c,
+                                                           int32_t *inv_x, int32_t *inv_y, int8_t *inv_c) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const unsigned long long ck = conf_key[c], ik = inv_key[c];
+    if (ck == ~0ull) { conf_x[c] = 0; conf_y[c] = 0; conf_d[c] = 0.0f; conf_c[c] = (int8_t)t_low; }
+    else {
+        const unsigned p = (unsigned)(ck & 0xffffffffu);
+        const int u = pts_xy[2 * p], v = pts_xy[2 * p + 1];
+        conf_x[c] = u; conf_y[c] = v; conf_d[c] = disp[(long)v * cols + u]; conf_c[c] = costs[(long)v * cols + u];
+    }
+    if (ik == ~0ull) { inv_x[c] = 0; inv_y[c] = 0; inv_c[c] = (int8_t)t_high; }
+    else {
+        const unsigned p = (unsigned)(ik & 0xffffffffu);
+        const int u = pts_xy[2 * p], v = pts_xy[2 * p + 1];
+        inv_x[c] = u; inv_y[c] = v; inv_c[c] = costs[(long)v * cols + u];
+    }
+}
+
+SVX_API int svx_refine(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float *disparities, const int8_t *costs,
+                       int rows, int cols, int t_low, int t_high, unsigned occ_grid_size,
+                       float *final_disparities, int8_t *final_costs,
+                       int32_t *conf_x, int32_t *conf_y, float *conf_d, int8_t *conf_c,
+                       int32_t *inv_x, int32_t *inv_y, int8_t *inv_c) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, disparities && costs && final_disparities && final_costs, SVX_ERR_INVALID_ARG, "svx_refine: null image pointer");
+    SVX_REQUIRE(ctx, conf_x && conf_y && conf_d && conf_c && inv_x && inv_y && inv_c, SVX_ERR_INVALID_ARG, "svx_refine: null grid pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_refine: empty image");
+    SVX_REQUIRE(ctx, occ_grid_size >= 1 && occ_grid_size <= 0x7fffffffu, SVX_ERR_INVALID_ARG, "svx_refine: occ_grid_size must be >= 1");
+    SVX_REQUIRE(ctx, n_pts >= 0, SVX_ERR_INVALID_ARG, "svx_refine: negative point count");
+    SVX_REQUIRE(ctx, n_pts == 0 || pts_xy, SVX_ERR_INVALID_ARG, "svx_refine: null point list");
+    SVX_REQUIRE(ctx, t_low >= -128 && t_low <= 127 && t_high >= -128 && t_high <= 127, SVX_ERR_INVALID_ARG, "svx_refine: thresholds must fit a signed char");
+    const int g = (int)occ_grid_size;
+    const int gw = cols / g + 1, gh = rows / g + 1;
+    const long n_cells = (long)gw * gh;
+    SVX_REQUIRE(ctx, n_cells <= 0x7fffffff, SVX_ERR_UNSUPPORTED, "svx_refine: grid too large");
+    void *ws;
+    rc = svx_ws_reserve(ctx, 2 * sizeof(unsigned long long) * (size_t)n_cells, &ws);
+    if (rc) return rc;
+    unsigned long long *ck = (unsigned long long *)ws, *ik = ck + n_cells;
+    SVX_HIP(ctx, hipMemsetAsync(ws, 0xff, 2 * sizeof(unsigned long long) * (size_t)n_cells, ctx->stream));
+    if (n_pts > 0) {
+        refine_points_kernel<<<svx_cdiv(n_pts, 256), 256, 0, ctx->stream>>>(pts_xy, n_pts, disparities, costs, rows, cols, t_low, t_high, g, gw,
+                                                                           final_disparities, final_costs, ck, ik);
+        SVX_LAUNCH_CHECK(ctx, "refine_points_kernel");
+    }
+    refine_cells_kernel<<<svx_cdiv(n_cells, 256), 256, 0, ctx->stream>>>(pts_xy, disparities, costs, cols, t_low, t_high, (int)n_cells, ck, ik,
+                                                                        conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c);
+    SVX_LAUNCH_CHECK(ctx, "refine_cells_kernel");
+    return SVX_OK;
+}
+
+// --------------------------------------------------------------- a12 -----
+#pragma clang fp contract(off)
+__device__ __forceinline__ double det3_first_row(const double m[3][3]) {
+    return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1])
+         - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+         + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+
+__global__ __launch_bounds__(256) void plane_fit_kernel(const int32_t *__restrict__ tri_xy, int n_tri, const float *__restrict__ disp,
+                                                        int rows, int cols, float *__restrict__ tri_abc) {
+#pragma clang fp contract(off)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tri) return;
+    double A[3][3], rhs[3];
+    for (int i = 0; i < 3; ++i) {
+        const int x = tri_xy[6 * t + 2 * i], y = tri_xy[6 * t + 2 * i + 1];
+        A[i][0] = (double)x; A[i][1] = (double)y; A[i][2] = 1.0;
+        rhs[i] = (x >= 0 && x < cols && y >= 0 && y < rows) ? (double)disp[(long)y * cols + x] : 0.0;
+    }
+    float abc[3] = {0.0f, 0.0f, 0.0f};
+    const double dA = det3_first_row(A);
+    if (dA != 0.0) {
+        for (int k = 0; k < 3; ++k) {
+            double M[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) M[i][j] = (j == k) ? rhs[i] : A[i][j];
+            abc[k] = (float)(det3_first_row(M) / dA);
+        }
+    }
+    tri_abc[3 * t] = abc[0]; tri_abc[3 * t + 1] = abc[1]; tri_abc[3 * t + 2] = abc[2];
+}
+
+SVX_API int svx_plane_fit(svx_ctx *ctx, const int32_t *tri_xy, int n_tri, const float *disparities, int rows, int cols, float *tri_abc) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, n_tri >= 0, SVX_ERR_INVALID_ARG, "svx_plane_fit: negative triangle count");
+    if (n_tri == 0) return SVX_OK;
+    SVX_REQUIRE(ctx, tri_xy && disparities && tri_abc, SVX_ERR_INVALID_ARG, "svx_plane_fit: null pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_plane_fit: empty image");
+    plane_fit_kernel<<<svx_cdiv(n_tri, 256), 256, 0, ctx->stream>>>(tri_xy, n_tri, disparities, rows, cols, tri_abc);
+    SVX_LAUNCH_CHECK(ctx, "plane_fit_kernel");
+    return SVX_OK;
+}
+
+// Rasterisation: one wavefront per triangle walks the triangle's bounding box;
+// a pixel is inside when the three integer edge functions agree in sign (zero
+// counts as inside).  Overlap on shared edges is resolved towards the lowest
+// triangle index with an atomicMin on a per-pixel owner map, then a second
+// pass evaluates the owner's plane.
+__device__ __forceinline__ bool tri_contains(const int32_t *v, int x, int y) {
+    const long e0 = (long)(v[2] - v[0]) * (y - v[1]) - (long)(v[3] - v[1]) * (x - v[0]);
+    const long e1 = (long)(v[4] - v[2]) * (y - v[3]) - (long)(v[5] - v[3]) * (x - v[2]);
+    const long e2 = (long)(v[0] - v[4]) * (y - v[5]) - (long)(v[1] - v[5]) * (x - v[4]);
+    return (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
+}
+
+__global__ __launch_bounds__(256) void raster_owner_kernel(const int32_t *__restrict__ tri_xy, int n_tri, int rows, int cols, unsigned *__restrict__ owner) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= n_tri) return;
+    int32_t v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = tri_xy[6 * t + i];
+    const long area2 = (long)(v[2] - v[0]) * (v[5] - v[1]) - (long)(v[3] - v[1]) * (v[4] - v[0]);
+    if (area2 == 0) return;   // degenerate triangles own nothing
+    const int xmin = max(0, min(v[0], min(v[2], v[4]))), xmax = min(cols - 1, max(v[0], max(v[2], v[4])));
+    const int ymin = max(0, min(v[1], min(v[3], v[5]))), ymax = min(rows - 1, max(v[1], max(v[3], v[5])));
+    if (xmin > xmax || ymin > ymax) return;
+    const int bw = xmax - xmin + 1;
+    const long total = (long)bw * (ymax - ymin + 1);
+    for (long i = lane; i < total; i += 64) {
+        const int y = ymin + (int)(i / bw), x = xmin + (int)(i % bw);
+        if (tri_contains(v, x, y)) atomicMin(owner + (long)y * cols + x, (unsigned)t);
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_eval_kernel(const unsigned *__restrict__ owner, const float *__restrict__ tri_abc, int rows, int cols,
+                                                          float *__restrict__ prior) {
+#pragma clang fp contract(off)
+    const long n = (long)rows * cols;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+        const unsigned t = owner[o];
+        if (t == 0xffffffffu) continue;
+        const int y = (int)(o / cols), x = (int)(o - (long)y * cols);
+        const float a = tri_abc[3 * t], b = tri_abc[3 * t + 1], c = tri_abc[3 * t + 2];
+        prior[o] = (float)((double)a * (double)x + (double)b * (double)y + (double)c);
+    }
+}
+
+SVX_API int svx_plane_prior_raster(svx_ctx *ctx, const int32_t *tri_xy, const float *tri_abc, int n_tri, int rows, int cols, float *prior) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, n_tri >= 0, SVX_ERR_INVALID_ARG, "svx_plane_prior_raster: negative triangle count");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_plane_prior_raster: empty image");
+    SVX_REQUIRE(ctx, prior != nullptr, SVX_ERR_INVALID_ARG, "svx_plane_prior_raster: null prior map");
+    if (n_tri == 0) return SVX_OK;
+    SVX_REQUIRE(ctx, tri_xy && tri_abc, SVX_ERR_INVALID_ARG, "svx_plane_prior_raster: null triangle pointer");
+    const size_t n = (size_t)rows * cols;
+    void *ws;
+    rc = svx_ws_reserve(ctx, n * sizeof(unsigned), &ws);
+    if (rc) return rc;
+    SVX_HIP(ctx, hipMemsetAsync(ws, 0xff, n * sizeof(unsigned), ctx->stream));
+    raster_owner_kernel<<<svx_cdiv(n_tri, 4), 256, 0, ctx->stream>>>(tri_xy, n_tri, rows, cols, (unsigned *)ws);
+    SVX_LAUNCH_CHECK(ctx, "raster_owner_kernel");
+    unsigned grid = svx_cdiv((long)n, 256);
+    if (grid > 4096) grid = 4096;
+    raster_eval_kernel<<<grid, 256, 0, ctx->stream>>>((const unsigned *)ws, tri_abc, rows, cols, prior);
+    SVX_LAUNCH_CHECK(ctx, "raster_eval_kernel");
+    return SVX_OK;
+}

@@ -1,0 +1,40 @@
+"""CPU-side checks of the C-ABI library: it loads, and exports every symbol include/svx.h declares."""
+import ctypes as C
+import os
+import re
+
+import stereovision_amd as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "svx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(svx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(S.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(S.lib_path())
+    for name in _declared():
+        assert hasattr(lib, name), name
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    lib = S.load_library()
+    assert lib.svx_version() == 100
+    assert lib.svx_strerror(-2) == b"Mismatching image sizes"
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        assert lib.svx_create(0, C.byref(h)) == -5      # SVX_ERR_NO_DEVICE, never a silent CPU path
+        try:
+            S.Context(0)
+        except S.SvxError as e:
+            assert e.code == -5
+        else:
+            raise AssertionError("Context() must raise without a GPU")

@@ -1,0 +1,349 @@
+"""GPU parity tests: every libsvx entry point, called through the C ABI (ctypes), against the CPU
+oracle on the same seeded inputs.  Integer / index results must be bit-exact; the only floating
+point outputs (plane parameters and the rasterised prior) are compared bit-exactly too because
+both sides evaluate the same double-precision expressions without contraction, with a 1e-3 px
+fallback tolerance stated where it is used."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_kat.json")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import stereovision_amd as S
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    c = S.Context(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def dev_u32(a):
+    return dev(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32))
+
+
+def rand_img(rng, rows, cols):
+    return rng.integers(0, 256, size=(rows, cols), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ a1 / a2
+def test_u8_to_s8(ctx):
+    rng = np.random.default_rng(0)
+    for shape in [(1, 1), (3, 5), (16, 64), (37, 129), (2, 33, 48)]:
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        got = ctx.u8_to_s8(dev(a)).cpu().numpy()
+        assert np.array_equal(got, O.u8_to_s8(a))
+
+
+@pytest.mark.parametrize("rows,cols", [(32, 64), (5, 8), (8, 4), (37, 132), (48, 256), (50, 260), (33, 67), (19, 21), (6, 5)])
+@pytest.mark.parametrize("layout", ["sse24", "generic25"])
+def test_census_matches_oracle(ctx, rows, cols, layout):
+    import stereovision_amd as S
+    rng = np.random.default_rng(rows * 1000 + cols)
+    img = rand_img(rng, rows, cols)
+    flag = S.CENSUS_SSE24 if layout == "sse24" else S.CENSUS_GENERIC25
+    sentinel = 0x5A5A5A5A
+    want = O.census5x5(O.u8_to_s8(img), layout, out=np.full((rows, cols), sentinel, np.uint32))
+    # fused u8 entry point, untouched pixels keep the caller's content
+    out = dev_u32(np.full((rows, cols), sentinel, np.uint32))
+    got = u32(ctx.census5x5(dev(img), flag, out=out))
+    assert np.array_equal(got, want)
+    # s8 entry point + ZERO_REST
+    want0 = O.census5x5(O.u8_to_s8(img), layout)
+    out = dev_u32(np.full((rows, cols), sentinel, np.uint32))
+    got0 = u32(ctx.census5x5(dev(O.u8_to_s8(img)), flag | S.CENSUS_ZERO_REST, out=out))
+    assert np.array_equal(got0, want0)
+
+
+def test_census_batched_frames_are_independent(ctx):
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, size=(3, 24, 64), dtype=np.uint8)
+    got = u32(ctx.census5x5(dev(imgs)))
+    for f in range(3):
+        assert np.array_equal(got[f], O.census5x5(O.u8_to_s8(imgs[f])))
+
+
+def test_census_golden(ctx):
+    left, right = O.kat_images()
+    cr = u32(ctx.census5x5(dev(right)))
+    cl = u32(ctx.census5x5(dev(left)))
+    for s in KAT["census_sse_right_samples"]:
+        assert int(cr[s["y"], s["x"]]) == int(s["value"], 16)
+    want = KAT["census_sse_fnv_rows2_29_cols2_61"]
+    assert O.fnv(cr[2:30, 2:62].astype("<u4")) == want["right"]
+    assert O.fnv(cl[2:30, 2:62].astype("<u4")) == want["left"]
+
+
+# ------------------------------------------------------------------ a4
+@pytest.mark.parametrize("mode", ["5x6", "5x5"])
+def test_window_cost(ctx, mode):
+    import stereovision_amd as S
+    rng = np.random.default_rng(9)
+    rows, cols = 40, 72
+    a = rng.integers(0, 1 << 24, size=(rows, cols), dtype=np.uint32)
+    b = rng.integers(0, 1 << 24, size=(rows, cols), dtype=np.uint32)
+    n = 500
+    # includes points on the very border: the window leaves the row / the frame
+    rxy = np.stack([rng.integers(0, cols, n), rng.integers(0, rows, n)], 1).astype(np.int32)
+    pxy = np.stack([rng.integers(0, cols, n), rng.integers(0, rows, n)], 1).astype(np.int32)
+    got = ctx.census_window_cost(dev_u32(a), dev_u32(b), dev(rxy), dev(pxy),
+                                 S.WINDOW_5X6 if mode == "5x6" else S.WINDOW_5X5).cpu().numpy()
+    want = np.array([O.window_cost(a, b, int(r[0]), int(r[1]), int(p[0]), int(p[1]), mode) for r, p in zip(rxy, pxy)], np.int16)
+    assert np.array_equal(got, want)
+
+
+def test_window_cost_golden(ctx):
+    left, right = O.kat_images()
+    cl = ctx.census5x5(dev(left)); cr = ctx.census5x5(dev(right))
+    k = KAT["census_window_match"]
+    rx, ry = k["ref_left_xy"]
+    rxy = np.array([[rx, ry]] * len(k["vs_right_xy"]), np.int32)
+    pxy = np.array([[p[0], p[1]] for p in k["vs_right_xy"]], np.int32)
+    got = ctx.census_window_cost(cl, cr, dev(rxy), dev(pxy)).cpu().numpy()
+    assert list(got) == [p[2] for p in k["vs_right_xy"]]
+
+
+# ------------------------------------------------------------------ a8
+@pytest.mark.parametrize("rows,cols,max_disp", [(32, 64, 16), (24, 80, 200), (40, 132, 64), (9, 12, 5), (33, 67, 33), (64, 200, 128)])
+def test_dense_wta_matches_oracle(ctx, rows, cols, max_disp):
+    from stereovision_amd import synth
+    left, right, _ = synth.stereo_pair(rows, cols, min(max_disp, max(2, cols // 3)), seed=rows + cols)
+    cl = O.census5x5(O.u8_to_s8(left)); cr = O.census5x5(O.u8_to_s8(right))
+    want = O.dense_wta5x5(cl, cr, max_disp)
+    got = ctx.dense_wta5x5(dev_u32(cl), dev_u32(cr), max_disp).cpu().numpy()
+    assert np.array_equal(got, want)
+    fused = ctx.dense_census_wta(dev(left), dev(right), max_disp).cpu().numpy()
+    assert np.array_equal(fused, want)
+
+
+def test_dense_wta_random_census_ties(ctx):
+    """Few distinct descriptor values => many equal costs: exercises the smallest-disparity tie rule."""
+    rng = np.random.default_rng(2)
+    rows, cols, D = 30, 96, 40
+    cl = rng.integers(0, 3, size=(rows, cols)).astype(np.uint32) * 0x111
+    cr = rng.integers(0, 3, size=(rows, cols)).astype(np.uint32) * 0x111
+    want = O.dense_wta5x5(cl, cr, D)
+    got = ctx.dense_wta5x5(dev_u32(cl), dev_u32(cr), D).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_dense_wta_golden_and_batch(ctx):
+    left, right = O.kat_images()
+    k = KAT["dense_wta5x5"]
+    d = ctx.dense_census_wta(dev(left), dev(right), k["maxDisp"]).cpu().numpy()
+    for s in k["samples"]:
+        assert d[s["y"], s["x"]] == s["d"]
+    assert O.fnv(d[4:28, 4:60].astype("<f4")) == k["fnv_rows4_27_cols4_59_f32"]
+    from stereovision_amd import synth
+    ls, rs = synth.stereo_batch(48, 96, 24, 3, seed0=40)
+    got = ctx.dense_census_wta(dev(ls), dev(rs), 24).cpu().numpy()
+    for f in range(3):
+        want = O.dense_wta5x5(O.census5x5(O.u8_to_s8(ls[f])), O.census5x5(O.u8_to_s8(rs[f])), 24)
+        assert np.array_equal(got[f], want)
+
+
+def test_dense_wta_recovers_generating_field(ctx):
+    """Size-independent sanity property at the benchmark size: the WTA disparity equals the field the
+    pair was generated with at almost every pixel (the reference reaches 0.992-0.994 on such data)."""
+    from stereovision_amd import synth
+    rows, cols, D = 368, 1232, 128
+    left, right, field = synth.stereo_pair(rows, cols, D, seed=0)
+    d = ctx.dense_census_wta(dev(left), dev(right), D).cpu().numpy()
+    inner = (slice(8, rows - 8), slice(D + 8, cols - 8))
+    frac = float(np.mean(d[inner] == field[inner]))
+    assert frac > 0.97, frac
+    assert d[:2].max() == 0 and d[-2:].max() == 0 and d[:, :2].max() == 0 and d[:, -2:].max() == 0
+    assert d.max() <= D - 1 and d.min() >= 0
+    # linear check on a few full rows against the oracle (rows are independent given the census)
+    cl = O.census5x5(O.u8_to_s8(left)); cr = O.census5x5(O.u8_to_s8(right))
+    want = np.zeros((rows, cols), np.float32)
+    O.lib.orc_dense_wta5x5_rows(cl.ctypes.data, cr.ctypes.data, rows, cols, D, want.ctypes.data, 100, 104)
+    assert np.array_equal(d[100:104], want[100:104])
+
+
+# ------------------------------------------------------------------ a9
+def test_epipolar_match_batch(ctx):
+    from stereovision_amd import synth
+    rows, cols = 40, 120
+    left, right, _ = synth.stereo_pair(rows, cols, 30, seed=3)
+    cl = O.census5x5(O.u8_to_s8(left)); cr = O.census5x5(O.u8_to_s8(right))
+    rng = np.random.default_rng(4)
+    pts = np.stack([rng.integers(0, cols, 300), rng.integers(0, rows, 300)], 1).astype(np.int32)
+    pts[:8] = [[0, 0], [cols - 1, rows - 1], [6, 0], [7, 3], [cols - 1, 5], [2, rows - 1], [cols - 3, 2], [60, 20]]
+    for aggr, D in [(11, 64), (5, 16), (1, 200), (7, 70)]:
+        d, c = ctx.epipolar_match_batch(dev_u32(cl), dev_u32(cr), dev(pts), 5, aggr, D)
+        d, c = d.cpu().numpy(), c.cpu().numpy()
+        for i, (x, y) in enumerate(pts):
+            wd, wc = O.epipolar_match(cl, cr, 5, aggr, int(x), int(y), D)
+            assert (d[i], c[i]) == (wd, wc), (aggr, D, x, y)
+
+
+# ------------------------------------------------------------------ a10 / a11
+def _prior_case(rows, cols, seed, dense_pts):
+    from stereovision_amd import synth
+    left, right, field = synth.stereo_pair(rows, cols, 24, seed=seed)
+    cl = O.census5x5(O.u8_to_s8(left)); cr = O.census5x5(O.u8_to_s8(right))
+    rng = np.random.default_rng(seed)
+    prior = (field + rng.normal(0, 0.6, size=field.shape)).astype(np.float32)
+    prior[rng.random(field.shape) < 0.05] = -3.5     # negative priors: xR beyond x, no upper bound in the reference
+    prior[:, -3:] = -40.0                             # xR far beyond the row end: flat addressing
+    mask = rng.random((rows, cols)) < dense_pts
+    mask[:2] = mask[-2:] = False
+    mask[:, :2] = mask[:, -2:] = False
+    ys, xs = np.nonzero(mask)
+    pts = np.stack([xs, ys], 1).astype(np.int32)      # raster order
+    return cl, cr, prior, pts
+
+
+@pytest.mark.parametrize("rows,cols,grid", [(32, 64, 16), (50, 130, 64), (40, 96, 1), (33, 70, 7)])
+def test_cost_eval_and_refine(ctx, rows, cols, grid):
+    cl, cr, prior, pts = _prior_case(rows, cols, rows + grid, 0.4)
+    t_low, t_high = 2, 10
+    costs_w = np.full((rows, cols), t_high, np.int8)
+    O.cost_eval(cl, cr, pts, prior, costs_w)
+    costs_g = ctx.cost_eval(dev_u32(cl), dev_u32(cr), dev(pts), dev(prior), dev(np.full((rows, cols), t_high, np.int8)))
+    assert np.array_equal(costs_g.cpu().numpy(), costs_w)
+    fd_w = np.zeros((rows, cols), np.float32); fc_w = np.full((rows, cols), 25, np.int8)
+    g_w = O.refine(pts, prior, costs_w, t_low, t_high, grid, fd_w, fc_w)
+    fd_g = dev(np.zeros((rows, cols), np.float32)); fc_g = dev(np.full((rows, cols), 25, np.int8))
+    g_g = ctx.refine(dev(pts), dev(prior), costs_g, t_low, t_high, grid, fd_g, fc_g)
+    assert np.array_equal(fd_g.cpu().numpy().view(np.uint32), fd_w.view(np.uint32))
+    assert np.array_equal(fc_g.cpu().numpy(), fc_w)
+    assert (g_g["gw"], g_g["gh"]) == (g_w["gw"], g_w["gh"])
+    for key in ("conf_x", "conf_y", "conf_c", "inv_x", "inv_y", "inv_c"):
+        assert np.array_equal(g_g[key].cpu().numpy(), g_w[key]), key
+    assert np.array_equal(g_g["conf_d"].cpu().numpy().view(np.uint32), g_w["conf_d"].view(np.uint32))
+    # second iteration on the persisted final maps (finalCosts now holds real costs)
+    prior2 = (prior + 1.0).astype(np.float32)
+    costs_w2 = np.full((rows, cols), t_high, np.int8); O.cost_eval(cl, cr, pts, prior2, costs_w2)
+    O.refine(pts, prior2, costs_w2, t_low, t_high, max(1, grid // 2), fd_w, fc_w)
+    costs_g2 = ctx.cost_eval(dev_u32(cl), dev_u32(cr), dev(pts), dev(prior2), dev(np.full((rows, cols), t_high, np.int8)))
+    ctx.refine(dev(pts), dev(prior2), costs_g2, t_low, t_high, max(1, grid // 2), fd_g, fc_g)
+    assert np.array_equal(fd_g.cpu().numpy().view(np.uint32), fd_w.view(np.uint32))
+    assert np.array_equal(fc_g.cpu().numpy(), fc_w)
+
+
+def test_refine_empty_point_list(ctx):
+    rows, cols = 20, 40
+    prior = dev(np.zeros((rows, cols), np.float32)); costs = dev(np.full((rows, cols), 10, np.int8))
+    fd = dev(np.zeros((rows, cols), np.float32)); fc = dev(np.full((rows, cols), 25, np.int8))
+    g = ctx.refine(dev(np.zeros((0, 2), np.int32)), prior, costs, 2, 10, 16, fd, fc)
+    assert (g["conf_c"].cpu().numpy() == 2).all() and (g["inv_c"].cpu().numpy() == 10).all()
+    assert (g["conf_x"].cpu().numpy() == 0).all() and (g["conf_d"].cpu().numpy() == 0).all()
+
+
+def test_plane_prior_path_golden(ctx):
+    left, right = O.kat_images()
+    cl = ctx.census5x5(dev(left)); cr = ctx.census5x5(dev(right))
+    k = KAT["plane_prior_path"]
+    R, Cc = left.shape
+    yy, xx = np.mgrid[0:R, 0:Cc]
+    prior = ((np.float32(3.2) + np.float32(0.11) * yy.astype(np.float32)) + np.float32(0.004) * xx.astype(np.float32)).astype(np.float32)
+    pts = np.array([(x, y) for y in range(2, R - 2) for x in range(2, Cc - 2) if (x + 2 * y) % 3 == 0], np.int32)
+    costs = ctx.cost_eval(cl, cr, dev(pts), dev(prior), dev(np.full((R, Cc), k["costs_prefill"], np.int8)))
+    assert O.fnv(costs.cpu().numpy()) == k["fnv_costs_i8"]
+    fd = dev(np.zeros((R, Cc), np.float32)); fc = dev(np.full((R, Cc), k["finalCosts_init"], np.int8))
+    g = ctx.refine(dev(pts), dev(prior), costs, k["tLow"], k["tHigh"], k["occGridSize"], fd, fc)
+    assert O.fnv(fd.cpu().numpy()) == k["fnv_finalDisp_f32"]
+    assert O.fnv(fc.cpu().numpy()) == k["fnv_finalCosts_i8"]
+    for c in k["cells"]:
+        idx = c["j"] * g["gw"] + c["i"]
+        assert [int(g["conf_x"][idx]), int(g["conf_y"][idx]), int(g["conf_c"][idx])] == [c["conf"][0], c["conf"][1], c["conf"][3]]
+        assert [int(g["inv_x"][idx]), int(g["inv_y"][idx]), int(g["inv_c"][idx])] == c["inv"]
+    e = k["epipolar"]
+    ep = np.array([[q["x"], q["y"]] for q in e], np.int32)
+    d, c = ctx.epipolar_match_batch(cl, cr, dev(ep), 5, 11, 24)
+    assert [float(v) for v in d.cpu()] == [q["d"] for q in e] and [int(v) for v in c.cpu()] == [q["cost"] for q in e]
+
+
+# ------------------------------------------------------------------ a5 / a6
+def _features(rng, rows, cols, n, border=0):
+    xs = rng.integers(border, cols - border, n).astype(np.float32)
+    ys = rng.integers(border, rows - border, n).astype(np.float32)
+    return np.stack([xs, ys], 1)
+
+
+@pytest.mark.parametrize("seed,uniq,step", [(1, 0.7, 1), (2, 0.5, 2), (3, 0.9, 1), (4, 0.6, 3)])
+def test_sparse_match(ctx, seed, uniq, step):
+    from stereovision_amd import synth
+    rows, cols, D = 64, 160, 40
+    left, right, field = synth.stereo_pair(rows, cols, 24, seed=seed)
+    cl = O.census5x5(O.u8_to_s8(left)); cr = O.census5x5(O.u8_to_s8(right))
+    rng = np.random.default_rng(seed)
+    lf = _features(rng, rows, cols, 400)              # includes the top / bottom rows and the image border
+    # right features: true correspondences of half of the left ones plus clutter
+    rf = np.concatenate([np.stack([lf[:200, 0] - field[lf[:200, 1].astype(int), lf[:200, 0].astype(int)], lf[:200, 1]], 1),
+                         _features(rng, rows, cols, 500)]).astype(np.float32)
+    rf[:, 0] = np.clip(rf[:, 0], 0, cols - 1)
+    if seed == 3:                                      # sub-pixel coordinates exercise the +0.5 rounding
+        lf += rng.uniform(-0.49, 0.49, lf.shape).astype(np.float32)
+        rf += rng.uniform(-0.49, 0.49, rf.shape).astype(np.float32)
+        lf = np.clip(lf, 0, [cols - 1, rows - 1]).astype(np.float32); rf = np.clip(rf, 0, [cols - 1, rows - 1]).astype(np.float32)
+    wl, wr, wc = O.sparse_match(cl, cr, lf, rf, D, 1.0, uniq, step)
+    gl, gr, gc = ctx.sparse_match(dev_u32(cl), dev_u32(cr), lf, rf, D, 1.0, uniq, step)
+    assert np.array_equal(gl, wl) and np.array_equal(gr, wr) and np.array_equal(gc, wc)
+    assert (wr >= 0).sum() > 20
+
+
+def test_sparse_match_edge_cases(ctx):
+    import stereovision_amd as S
+    cl = dev_u32(np.zeros((16, 32), np.uint32)); cr = dev_u32(np.zeros((16, 32), np.uint32))
+    l, r, c = ctx.sparse_match(cl, cr, np.zeros((0, 2), np.float32), np.ones((3, 2), np.float32), 8)
+    assert len(l) == 0
+    l, r, c = ctx.sparse_match(cl, cr, np.ones((3, 2), np.float32), np.zeros((0, 2), np.float32), 8)
+    assert len(l) == 0
+    with pytest.raises(S.SvxError) as e:
+        ctx.sparse_match(cl, dev_u32(np.zeros((16, 48), np.uint32)), np.ones((1, 2), np.float32), np.ones((1, 2), np.float32), 8)
+    assert "Mismatching image sizes" in str(e.value)
+
+
+# ------------------------------------------------------------------ a12
+def test_plane_fit_and_raster(ctx):
+    rng = np.random.default_rng(8)
+    rows, cols = 60, 90
+    disp = rng.uniform(0, 60, size=(rows, cols)).astype(np.float32)
+    # a fan triangulation of random integer points plus degenerate and out-of-frame triangles
+    pts = np.stack([rng.integers(0, cols, 40), rng.integers(0, rows, 40)], 1)
+    tris = []
+    for i in range(60):
+        a, b, c = rng.choice(len(pts), 3, replace=False)
+        tris.append([*pts[a], *pts[b], *pts[c]])
+    tris.append([5, 5, 10, 10, 20, 20])       # collinear
+    tris.append([3, 3, 3, 3, 9, 1])           # repeated vertex
+    tris = np.array(tris, np.int32)
+    abc_w = np.stack([O.plane_fit([[t[0], t[1], disp[t[1], t[0]]], [t[2], t[3], disp[t[3], t[2]]], [t[4], t[5], disp[t[5], t[4]]]]) for t in tris])
+    abc_g = ctx.plane_fit(dev(tris), dev(disp))
+    assert np.array_equal(abc_g.cpu().numpy().view(np.uint32), abc_w.view(np.uint32))
+    prior_w = np.full((rows, cols), -1.0, np.float32)
+    O.plane_prior_raster(tris, abc_w, rows, cols, prior_w)
+    prior_g = ctx.plane_prior_raster(dev(tris), abc_g, dev(np.full((rows, cols), -1.0, np.float32))).cpu().numpy()
+    assert np.array_equal(prior_g.view(np.uint32), prior_w.view(np.uint32))  # and therefore within 1e-3 px
+    assert (prior_w == -1.0).any() and (prior_w != -1.0).any()
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_argument_errors(ctx):
+    import stereovision_amd as S
+    img = dev(np.zeros((8, 16), np.uint8))
+    with pytest.raises(S.SvxError):
+        ctx.census5x5(img, flags=7)
+    with pytest.raises(S.SvxError):
+        ctx.dense_census_wta(img, img, 0)
+    with pytest.raises(S.SvxError):
+        ctx.dense_census_wta(img, dev(np.zeros((8, 32), np.uint8)), 8)
