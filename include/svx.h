@@ -162,6 +162,15 @@ int svx_plane_fit(svx_ctx *ctx, const int32_t *tri_xy, int n_tri, const float *d
 int svx_plane_prior_raster(svx_ctx *ctx, const int32_t *tri_xy, const float *tri_abc, int n_tri,
                            int rows, int cols, float *prior);
 
+/* ---- measurement aid (no counterpart in the reference) ---------------------
+ * Sustained issue rate, in lane-instructions per second, of the VALU pairs the
+ * dense matcher is built from, with `waves_per_simd` wavefronts resident per
+ * SIMD.  mode 0 = v_xor_b32 + v_bcnt_u32_b32, the measured peak the
+ * popcount-bound kernel is priced against; modes 1..7 pair v_xor/v_sub with
+ * v_add_u32, v_add3_u32, v_min_u32, DPP v_add_u32, v_pk_add_u16,
+ * v_mad_u32_u24 and v_lshl_add_u32.  Synchronous. */
+int svx_probe_valu_rate(svx_ctx *ctx, int mode, int waves_per_simd, int iters, double *lane_ops_per_s);
+
 #ifdef __cplusplus
 }
 #endif

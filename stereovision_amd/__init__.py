@@ -16,6 +16,8 @@ from ._lib import (  # noqa: F401
     WINDOW_5X6,
     WINDOW_5X5,
     EXPORTS,
+    DOMINANT_KERNEL,
+    dominant_kernel_timer,
 )
 
 __all__ = ["Context", "SvxError", "lib_path", "load_library", "CENSUS_SSE24", "CENSUS_GENERIC25",

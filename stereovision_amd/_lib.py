@@ -39,6 +39,7 @@ EXPORTS = {
     "svx_refine": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, C.c_uint, _vp, _vp] + [_vp] * 7),
     "svx_plane_fit": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
     "svx_plane_prior_raster": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
 }
 
 
@@ -134,6 +135,12 @@ class Context:
 
     def synchronize(self):
         self._call("svx_synchronize")
+
+    def probe_valu_rate(self, mode=0, waves_per_simd=4, iters=20000):
+        """Measured VALU pair rate in lane-instructions/s; mode 0 = v_xor + v_bcnt (a measurement aid)."""
+        r = C.c_double(0.0)
+        self._call("svx_probe_valu_rate", int(mode), int(waves_per_simd), int(iters), C.byref(r))
+        return r.value
 
     # ---- a1 / a2 ----
     def u8_to_s8(self, src, out=None):
@@ -267,3 +274,15 @@ class Context:
         self._call("svx_plane_prior_raster", _dptr(tri_xy), _dptr(tri_abc), tri_xy.shape[0], prior.shape[0], prior.shape[1],
                    _dptr(prior))
         return prior
+
+
+# ---- measurement helpers used by bench.py -------------------------------------------------------
+DOMINANT_KERNEL = "dense_wta5x5_sweep_kernel"
+
+
+def dominant_kernel_timer(ctx, left, right, max_disp, disp):
+    """Returns a zero-argument callable that launches exactly the dominant kernel of the hot path
+    (the dense WTA) once, on inputs prepared here, so that it can be bracketed by stream events."""
+    cl = ctx.census5x5(left, CENSUS_SSE24 | CENSUS_ZERO_REST)
+    cr = ctx.census5x5(right, CENSUS_SSE24 | CENSUS_ZERO_REST)
+    return lambda: ctx.dense_wta5x5(cl, cr, max_disp, out=disp)

@@ -1,10 +1,22 @@
 // a8: dense winner-takes-all over 5x5-aggregated census Hamming costs (gfx950).
+//
+// Two kernels:
+//   dense_wta5x5_plain_kernel  one thread per pixel, 25 popcounts per disparity; the simplest
+//                              correct statement of the search, used for sizes the sweep kernel
+//                              does not cover (max_disp > 1024).
+//   dense_wta5x5_sweep_kernel  the fast path, VALU-popcount bound.  One wavefront owns a block of
+//                              16 output columns of one row strip; its 64 lanes are 64 consecutive
+//                              disparities.  It sweeps down the rows and keeps everything in
+//                              registers: per row and column one v_xor + v_bcnt accumulates the
+//                              per-pixel Hamming distance into a running column sum, a prefix sum
+//                              along x turns five columns into one subtraction, and a ring of the
+//                              last five rows' window sums turns five rows into one addition.  The
+//                              disparity is folded into the low bits of the cost so that the
+//                              argmin over the 64 lanes is a plain min, done as a DPP butterfly that
+//                              reduces the 16 columns at once.  No cost volume exists anywhere.
 #include "svx_common.hpp"
 
 // ---------------------------------------------------------------------------
-// Plain formulation: one thread per pixel, every disparity, 25 popcounts each.
-// Kept as the simplest correct statement of the search (any size, any
-// max_disp); the tiled kernel below is the fast path.
 __global__ __launch_bounds__(256) void dense_wta5x5_plain_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                                  int rows, int cols, int max_disp, float *__restrict__ disp_all,
                                                                  int write_border) {
@@ -36,11 +48,259 @@ __global__ __launch_bounds__(256) void dense_wta5x5_plain_kernel(const uint32_t 
     disp[(long)y * cols + x] = (float)(x - bestx);
 }
 
+// ---------------------------------------------------------------------------
+// Sweep kernel.
+constexpr int SW_T = 16;             // output columns per wavefront
+constexpr int SW_C = SW_T + 4;       // census columns touched per row (2-column halo each side)
+constexpr int SW_SLOTS = 4;          // staged rows in the wavefront's private LDS ring
+constexpr int SW_SLOT_WORDS = 128;   // right: words 0..82 (columns xq .. xq+82), left: words 96..115
+constexpr int SW_LEFT_OFF = 96;
+constexpr int SW_KEY_SHIFT = 10;     // key = cost << 10 | d  (d < 1024)
+constexpr int SW_DMASK = (1 << SW_KEY_SHIFT) - 1;
+constexpr uint32_t SW_INVALID = 0x40000000u;   // canonical key of "no admissible disparity": decodes to d = 0
+constexpr int SW_MAX_STRIP = 96;     // rows per strip (best-key store in LDS: strip x 16 words per wavefront)
+
+struct SweepState {
+    uint32_t C[SW_C];          // running column sums of per-pixel Hamming distances (prefix over rows)
+    uint32_t ring[5][SW_T];    // signed window sums of the five previous rows (sign alternates by row)
+};
+
+// Argmin / argmax butterfly over the 64 lanes for 16 registers at once.
+// In : k[i] = key of column i in every lane (lane = disparity).
+// Out: lanes 0..15 (and every other 16-lane row) hold the reduced key of column (lane & 15).
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t reduce16(const uint32_t (&k)[SW_T], int lane) {
+    uint32_t r[8], q[4], u[4];
+    // stage A: lanes l and l+8 of each 16-lane row; banks 0,1 keep columns 0..7, banks 2,3 columns 8..15
+#define SVX_STAGE_A(OP)                                                                                        \
+    asm volatile("s_nop 1\n\t"                                                                                 \
+                 OP " %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"  OP " %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                 OP " %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" OP " %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+                 OP " %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" OP " %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+                 OP " %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" OP " %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+                 OP " %0, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" OP " %1, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" \
+                 OP " %2, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" OP " %3, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" \
+                 OP " %4, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" OP " %5, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" \
+                 OP " %6, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" OP " %7, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc\n\t" \
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])            \
+                 : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]),                         \
+                   "v"(k[8]), "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]), "v"(k[15]))
+    // stage B: lanes l and l+-4; bank b ends up with column (i + 4b) of register i
+#define SVX_STAGE_B(OP)                                                                                        \
+    asm volatile("s_nop 1\n\t"                                                                                 \
+                 OP " %0, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t" OP " %1, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"   \
+                 OP " %2, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t" OP " %3, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"   \
+                 OP " %0, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t" OP " %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"   \
+                 OP " %2, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t" OP " %3, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t" \
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])                                                                \
+                 : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]))
+    // stage C1: lanes l and l^1 inside every quad
+#define SVX_STAGE_C1(OP)                                                                                       \
+    asm volatile("s_nop 1\n\t"                                                                                 \
+                 OP " %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" OP " %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 OP " %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" OP " %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]) : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]))
+    // stage C2: lanes l and l^2 inside every quad
+#define SVX_STAGE_C2(OP, a, b)                                                                                 \
+    asm volatile("s_nop 1\n\t"                                                                                 \
+                 OP " %0, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" OP " %1, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+                 : "=&v"(a), "=&v"(b) : "v"(w0), "v"(w1))
+    if (IS_MAX) { SVX_STAGE_A("v_max_i32_dpp"); SVX_STAGE_B("v_max_i32_dpp"); SVX_STAGE_C1("v_max_i32_dpp"); }
+    else        { SVX_STAGE_A("v_min_u32_dpp"); SVX_STAGE_B("v_min_u32_dpp"); SVX_STAGE_C1("v_min_u32_dpp"); }
+    // odd lanes take the pair result of the odd register
+    const uint32_t w0 = (lane & 1) ? u[1] : u[0];
+    const uint32_t w1 = (lane & 1) ? u[3] : u[2];
+    uint32_t x0, x1;
+    if (IS_MAX) { SVX_STAGE_C2("v_max_i32_dpp", x0, x1); } else { SVX_STAGE_C2("v_min_u32_dpp", x0, x1); }
+    uint32_t z = (lane & 2) ? x1 : x0;     // lane (l & 15) now holds column (l & 15), reduced over its 16-lane row
+    // stage D: across the four 16-lane rows
+    uint32_t o = (uint32_t)__shfl_xor((int)z, 16, 64);
+    z = IS_MAX ? (uint32_t)max((int)z, (int)o) : min(z, o);
+    o = (uint32_t)__shfl_xor((int)z, 32, 64);
+    z = IS_MAX ? (uint32_t)max((int)z, (int)o) : min(z, o);
+    return z;
+#undef SVX_STAGE_A
+#undef SVX_STAGE_B
+#undef SVX_STAGE_C1
+#undef SVX_STAGE_C2
+}
+
+// One census row of the sweep.  R = row counter modulo 10 (ring slot R % 5, sign (-1)^R).
+template <int R, bool MASKED>
+__device__ __forceinline__ uint32_t sweep_row(SweepState &st, const uint32_t *__restrict__ slot, int lane, uint32_t d, int xlim_base, int dmax) {
+    constexpr int S = R % 5;
+    constexpr bool ODD = (R & 1) != 0;
+    // left words: identical in every lane (LDS broadcast); right words: lane l reads column xq + (63 - l) + j
+    uint32_t cl[SW_C], cr[SW_C];
+    const uint4 *lp = reinterpret_cast<const uint4 *>(slot + SW_LEFT_OFF);
+#pragma unroll
+    for (int j = 0; j < SW_C / 4; ++j) {
+        const uint4 v = lp[j];
+        cl[4 * j] = v.x; cl[4 * j + 1] = v.y; cl[4 * j + 2] = v.z; cl[4 * j + 3] = v.w;
+    }
+    const uint32_t *rp = slot + (63 - lane);
+#pragma unroll
+    for (int j = 0; j < SW_C; ++j) cr[j] = rp[j];
+#pragma unroll
+    for (int j = 0; j < SW_C; ++j) st.C[j] += (uint32_t)__builtin_popcount(cl[j] ^ cr[j]);
+    // prefix sum along x, scaled so that the disparity fits below the cost
+    uint32_t ip[SW_C];
+    ip[0] = st.C[0] << SW_KEY_SHIFT;
+#pragma unroll
+    for (int j = 1; j < SW_C; ++j) ip[j] = (st.C[j] << SW_KEY_SHIFT) + ip[j - 1];
+    uint32_t key[SW_T];
+#pragma unroll
+    for (int i = 0; i < SW_T; ++i) {
+        // window of columns i .. i+4  (output column i sits at census column i+2)
+        const uint32_t hi = ip[i + 4], lo = i == 0 ? 0u : ip[i - 1];
+        const uint32_t v = ODD ? lo - hi : hi - lo;
+        key[i] = v + st.ring[S][i] + d;       // even rows: cost<<10 + d ; odd rows: -(cost<<10) + (1023 - d)
+        st.ring[S][i] = v;
+    }
+    if (MASKED) {
+        // disparities that would put the right window left of column 5, or beyond max_disp, never win
+#pragma unroll
+        for (int i = 0; i < SW_T; ++i) {
+            const bool ok = (int)(ODD ? SW_DMASK - d : d) <= min(xlim_base + i, dmax);
+            key[i] = ok ? key[i] : (ODD ? (uint32_t)SW_DMASK - SW_INVALID : SW_INVALID);
+        }
+    }
+    const uint32_t z = reduce16<ODD>(key, lane);
+    return ODD ? (uint32_t)SW_DMASK - z : z;    // canonical key: cost << 10 | d
+}
+
+// Sweeps one 64-disparity chunk of one (strip, 16-column block) and merges its winners into `best`.
+template <bool MASKED>
+__device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int cols, int max_disp,
+                                            int xb, int y_lo, int n_rows, int chunk, int lane,
+                                            uint32_t (*stage)[SW_SLOT_WORDS], uint32_t (*best)[SW_T]) {
+    const int dbase = chunk << 6;
+    const uint32_t d = (uint32_t)(dbase + lane);
+    const uint32_t d_odd = (uint32_t)SW_DMASK - d;
+    const int xq = xb - 2 - dbase - 63;             // right column held in stage word 0
+    const int xlim_base = xb - 5;                   // admissible: d <= xlim_base + i
+    const int dmax = max_disp - 1;
+    SweepState st;
+#pragma unroll
+    for (int j = 0; j < SW_C; ++j) st.C[j] = 0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int i = 0; i < SW_T; ++i) st.ring[s][i] = 0;
+
+    // staging: lane l fetches right columns xq+l and xq+64+l (l < 19) and left column xb-2+l (l < 20)
+    auto fetch = [&](int r, uint32_t &g0, uint32_t &g1, uint32_t &g2) {
+        const long ro = (long)(y_lo - 2 + r) * cols;
+        const int c0 = xq + lane, c1 = xq + 64 + lane, c2 = xb - 2 + lane;
+        g0 = (c0 >= 0 && c0 < cols) ? cr[ro + c0] : 0u;
+        g1 = (lane < 19 && c1 >= 0 && c1 < cols) ? cr[ro + c1] : 0u;
+        g2 = (lane < SW_C && c2 >= 0 && c2 < cols) ? cl[ro + c2] : 0u;
+    };
+    auto stash = [&](int r, uint32_t g0, uint32_t g1, uint32_t g2) {
+        uint32_t *s = stage[r & (SW_SLOTS - 1)];
+        s[lane] = g0;
+        if (lane < 32) s[64 + lane] = g1;
+        if (lane < SW_C) s[SW_LEFT_OFF + lane] = g2;
+        __builtin_amdgcn_wave_barrier();            // the rows are read back by other lanes of this wavefront
+    };
+    uint32_t g0, g1, g2;
+    fetch(0, g0, g1, g2);
+    stash(0, g0, g1, g2);
+    if (n_rows > 1) fetch(1, g0, g1, g2);
+
+#define SVX_ROW(RR)                                                                                   \
+    if (r0 + RR < n_rows) {                                                                           \
+        const int r = r0 + RR;                                                                        \
+        if (r + 1 < n_rows) stash(r + 1, g0, g1, g2);                                                 \
+        if (r + 2 < n_rows) fetch(r + 2, g0, g1, g2);                                                 \
+        const uint32_t zk = sweep_row<RR, MASKED>(st, stage[r & (SW_SLOTS - 1)], lane, (RR & 1) ? d_odd : d, xlim_base, dmax); \
+        if (r >= 4 && lane < SW_T) {     /* output row y_lo + r - 4; lanes 0..15 hold the 16 columns */ \
+            uint32_t *b = &best[r - 4][lane];                                                         \
+            *b = chunk == 0 ? zk : min(*b, zk);                                                       \
+        }                                                                                             \
+    }
+    for (int r0 = 0; r0 < n_rows; r0 += 10) {
+        SVX_ROW(0) SVX_ROW(1) SVX_ROW(2) SVX_ROW(3) SVX_ROW(4)
+        SVX_ROW(5) SVX_ROW(6) SVX_ROW(7) SVX_ROW(8) SVX_ROW(9)
+    }
+#undef SVX_ROW
+}
+
+// grid: (x-blocks of 16 columns / 4, strips, frames); block: 256 threads = 4 independent wavefronts.
+__global__ __launch_bounds__(256) void dense_wta5x5_sweep_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
+                                                                 int rows, int cols, int max_disp, int strip_rows,
+                                                                 float *__restrict__ disp_all, int write_border) {
+    __shared__ uint32_t lds_stage[4][SW_SLOTS][SW_SLOT_WORDS];
+    __shared__ uint32_t lds_best[4][SW_MAX_STRIP][SW_T];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long n = (long)rows * cols;
+    const uint32_t *cl = cl_all + (long)blockIdx.z * n;
+    const uint32_t *cr = cr_all + (long)blockIdx.z * n;
+    float *disp = disp_all + (long)blockIdx.z * n;
+    const int xb = (blockIdx.x * 4 + wave) * SW_T;          // first output column of this wavefront
+    if (xb >= cols) return;
+    const int ys = blockIdx.y * strip_rows;                 // first output row of the strip
+    const int y_lo = max(ys, 2), y_hi = min(ys + strip_rows, rows - 2);   // output rows [y_lo, y_hi)
+    uint32_t (*stage)[SW_SLOT_WORDS] = lds_stage[wave];
+    uint32_t (*best)[SW_T] = lds_best[wave];
+
+    if (y_lo < y_hi) {
+        const int n_out = y_hi - y_lo;
+        const int n_rows = n_out + 4;                       // census rows y_lo-2 .. y_hi+1
+        const int n_chunks = (max_disp + 63) >> 6;
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const int dbase = chunk << 6;
+            // no disparity of this chunk is admissible for any column of the block
+            if (chunk > 0 && dbase > xb + SW_T - 1 - 5) break;
+            // masking is needed when some (column, lane) pair is inadmissible
+            const bool masked = (dbase + 63 > xb - 5) || (dbase + 63 > max_disp - 1);
+            if (masked) sweep_chunk<true>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
+            else sweep_chunk<false>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // write-out: 4 rows x 16 columns per pass
+        for (int o = (lane >> 4); o < n_out; o += 4) {
+            const int x = xb + (lane & 15), y = y_lo + o;
+            if (x < cols) {
+                float v = 0.0f;
+                const bool inner = x >= 2 && x < cols - 2;
+                if (inner && x >= 5) v = (float)(best[o][lane & 15] & SW_DMASK);
+                if (inner || write_border) disp[(long)y * cols + x] = v;
+            }
+        }
+    }
+    if (write_border) {
+        // rows of this strip outside [2, rows-2)
+        for (int y = ys + (lane >> 4); y < min(ys + strip_rows, rows); y += 4) {
+            const int x = xb + (lane & 15);
+            if ((y < 2 || y >= rows - 2) && x < cols) disp[(long)y * cols + x] = 0.0f;
+        }
+    }
+}
+
 static int dense_args_ok(svx_ctx *ctx, const void *a, const void *b, const void *c, int rows, int cols, int n_frames, int max_disp) {
     SVX_REQUIRE(ctx, a && b && c, SVX_ERR_INVALID_ARG, "dense_wta: null pointer");
     SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "dense_wta: empty image");
     SVX_REQUIRE(ctx, max_disp >= 1, SVX_ERR_INVALID_ARG, "dense_wta: max_disp must be >= 1");
     SVX_REQUIRE(ctx, n_frames <= 65535, SVX_ERR_UNSUPPORTED, "dense_wta: more than 65535 frames per call");
+    return SVX_OK;
+}
+
+static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
+                        float *disparity, int write_border) {
+    if (max_disp > SW_DMASK + 1) {
+        dim3 grid(svx_cdiv(cols, 64), svx_cdiv(rows, 4), n_frames);
+        dense_wta5x5_plain_kernel<<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity, write_border);
+        SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_plain_kernel");
+        return SVX_OK;
+    }
+    // strips: as tall as the LDS best-key store allows, evened out over the image
+    const int n_strips = (rows + SW_MAX_STRIP - 1) / SW_MAX_STRIP;
+    const int strip_rows = (rows + n_strips - 1) / n_strips;
+    dim3 grid(svx_cdiv(cols, SW_T * 4), svx_cdiv(rows, strip_rows), n_frames);
+    dense_wta5x5_sweep_kernel<<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border);
+    SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_sweep_kernel");
     return SVX_OK;
 }
 
@@ -50,10 +310,7 @@ SVX_API int svx_dense_wta5x5(svx_ctx *ctx, const uint32_t *census_left, const ui
     if (rc) return rc;
     rc = dense_args_ok(ctx, census_left, census_right, disparity, rows, cols, n_frames, max_disp);
     if (rc) return rc;
-    dim3 grid(svx_cdiv(cols, 64), svx_cdiv(rows, 4), n_frames);
-    dense_wta5x5_plain_kernel<<<grid, 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, max_disp, disparity, 0);
-    SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_plain_kernel");
-    return SVX_OK;
+    return launch_dense(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disparity, 0);
 }
 
 SVX_API int svx_dense_census_wta_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right,
@@ -71,8 +328,5 @@ SVX_API int svx_dense_census_wta_u8(svx_ctx *ctx, const uint8_t *left, const uin
     if (rc) return rc;
     rc = svx_census5x5_u8(ctx, right, cr, rows, cols, n_frames, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST);
     if (rc) return rc;
-    dim3 grid(svx_cdiv(cols, 64), svx_cdiv(rows, 4), n_frames);
-    dense_wta5x5_plain_kernel<<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity, 1);
-    SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_plain_kernel");
-    return SVX_OK;
+    return launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1);
 }
