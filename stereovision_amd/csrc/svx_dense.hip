@@ -15,6 +15,7 @@
 //                              argmin over the 64 lanes is a plain min, done as a DPP butterfly that
 //                              reduces the 16 columns at once.  No cost volume exists anywhere.
 #include "svx_common.hpp"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dense_wta5x5_plain_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
@@ -52,10 +53,9 @@ __global__ __launch_bounds__(256) void dense_wta5x5_plain_kernel(const uint32_t 
 // Sweep kernel.
 constexpr int SW_T = 16;             // output columns per wavefront
 constexpr int SW_C = SW_T + 4;       // census columns touched per row (2-column halo each side)
-constexpr int SW_SLOTS = 4;          // staged rows in the wavefront's private LDS ring
-constexpr int SW_SLOT_WORDS = 128;   // right: words 0..82 (columns xq .. xq+82), left: words 96..115
-constexpr int SW_LEFT_OFF = 96;
-constexpr int SW_KEY_SHIFT = 10;     // key = cost << 10 | d  (d < 1024)
+constexpr int SW_SLOTS = 5;          // staged rows in the wavefront's private LDS ring (divides the 10-row group)
+constexpr int SW_SLOT_WORDS = 96;    // right census words of columns xq .. xq+82 (83 used)
+constexpr int SW_KEY_SHIFT = 10;     // key = cost << 10 | d  (d < 1024); the literal 10 also sits in sweep_row's asm
 constexpr int SW_DMASK = (1 << SW_KEY_SHIFT) - 1;
 constexpr uint32_t SW_INVALID = 0x40000000u;   // canonical key of "no admissible disparity": decodes to d = 0
 constexpr int SW_MAX_STRIP = 96;     // rows per strip (best-key store in LDS: strip x 16 words per wavefront)
@@ -67,7 +67,8 @@ struct SweepState {
 
 // Argmin / argmax butterfly over the 64 lanes for 16 registers at once.
 // In : k[i] = key of column i in every lane (lane = disparity).
-// Out: lanes 0..15 (and every other 16-lane row) hold the reduced key of column (lane & 15).
+// Out: lane l holds the key of column (l & 15) reduced over its own 16-lane row (16 disparities); the four
+//      rows are merged by the caller's LDS atomic.
 template <bool IS_MAX>
 __device__ __forceinline__ uint32_t reduce16(const uint32_t (&k)[SW_T], int lane) {
     uint32_t r[8], q[4], u[4];
@@ -113,11 +114,6 @@ __device__ __forceinline__ uint32_t reduce16(const uint32_t (&k)[SW_T], int lane
     uint32_t x0, x1;
     if (IS_MAX) { SVX_STAGE_C2("v_max_i32_dpp", x0, x1); } else { SVX_STAGE_C2("v_min_u32_dpp", x0, x1); }
     uint32_t z = (lane & 2) ? x1 : x0;     // lane (l & 15) now holds column (l & 15), reduced over its 16-lane row
-    // stage D: across the four 16-lane rows
-    uint32_t o = (uint32_t)__shfl_xor((int)z, 16, 64);
-    z = IS_MAX ? (uint32_t)max((int)z, (int)o) : min(z, o);
-    o = (uint32_t)__shfl_xor((int)z, 32, 64);
-    z = IS_MAX ? (uint32_t)max((int)z, (int)o) : min(z, o);
     return z;
 #undef SVX_STAGE_A
 #undef SVX_STAGE_B
@@ -125,29 +121,29 @@ __device__ __forceinline__ uint32_t reduce16(const uint32_t (&k)[SW_T], int lane
 #undef SVX_STAGE_C2
 }
 
-// One census row of the sweep.  R = row counter modulo 10 (ring slot R % 5, sign (-1)^R).
-template <int R, bool MASKED>
-__device__ __forceinline__ uint32_t sweep_row(SweepState &st, const uint32_t *__restrict__ slot, int lane, uint32_t d, int xlim_base, int dmax) {
-    constexpr int S = R % 5;
-    constexpr bool ODD = (R & 1) != 0;
-    // left words: identical in every lane (LDS broadcast); right words: lane l reads column xq + (63 - l) + j
-    uint32_t cl[SW_C], cr[SW_C];
-    const uint4 *lp = reinterpret_cast<const uint4 *>(slot + SW_LEFT_OFF);
-#pragma unroll
-    for (int j = 0; j < SW_C / 4; ++j) {
-        const uint4 v = lp[j];
-        cl[4 * j] = v.x; cl[4 * j + 1] = v.y; cl[4 * j + 2] = v.z; cl[4 * j + 3] = v.w;
-    }
-    const uint32_t *rp = slot + (63 - lane);
+// One census row of the sweep, phase 1: fold the row into the running column sums.
+// cl: the 20 left words of the row (wavefront-uniform, in SGPRs); rp: this lane's view of the staged right
+// words, skewed by its disparity (lane l reads column xq + 63 - l + j).
+__device__ __forceinline__ void sweep_row_accumulate(SweepState &st, const uint32_t (&cl)[SW_C], const uint32_t *__restrict__ rp) {
+    uint32_t cr[SW_C];
 #pragma unroll
     for (int j = 0; j < SW_C; ++j) cr[j] = rp[j];
 #pragma unroll
     for (int j = 0; j < SW_C; ++j) st.C[j] += (uint32_t)__builtin_popcount(cl[j] ^ cr[j]);
+}
+
+// Phase 2: form the 16 window keys and reduce them over the lanes.
+// R = row counter modulo 10 (ring slot R % 5, sign (-1)^R).
+template <int R, bool MASKED>
+__device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, uint32_t d, int xlim_base, int dmax) {
+    constexpr int S = R % 5;
+    constexpr bool ODD = (R & 1) != 0;
     // prefix sum along x, scaled so that the disparity fits below the cost
     uint32_t ip[SW_C];
     ip[0] = st.C[0] << SW_KEY_SHIFT;
 #pragma unroll
-    for (int j = 1; j < SW_C; ++j) ip[j] = (st.C[j] << SW_KEY_SHIFT) + ip[j - 1];
+    for (int j = 1; j < SW_C; ++j)   // (C << 10) + previous in ONE instruction; opaque so that it is not re-associated
+        asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(ip[j]) : "v"(st.C[j]), "v"(ip[j - 1]));
     uint32_t key[SW_T];
 #pragma unroll
     for (int i = 0; i < SW_T; ++i) {
@@ -170,6 +166,8 @@ __device__ __forceinline__ uint32_t sweep_row(SweepState &st, const uint32_t *__
 }
 
 // Sweeps one 64-disparity chunk of one (strip, 16-column block) and merges its winners into `best`.
+// xb is the first output column; census columns xb-2 .. xb+17 are all inside the row (the caller
+// guarantees 2 <= xb <= cols-18).
 template <bool MASKED>
 __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int cols, int max_disp,
                                             int xb, int y_lo, int n_rows, int chunk, int lane,
@@ -188,36 +186,57 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
 #pragma unroll
         for (int i = 0; i < SW_T; ++i) st.ring[s][i] = 0;
 
-    // staging: lane l fetches right columns xq+l and xq+64+l (l < 19) and left column xb-2+l (l < 20)
-    auto fetch = [&](int r, uint32_t &g0, uint32_t &g1, uint32_t &g2) {
-        const long ro = (long)(y_lo - 2 + r) * cols;
-        const int c0 = xq + lane, c1 = xq + 64 + lane, c2 = xb - 2 + lane;
-        g0 = (c0 >= 0 && c0 < cols) ? cr[ro + c0] : 0u;
-        g1 = (lane < 19 && c1 >= 0 && c1 < cols) ? cr[ro + c1] : 0u;
-        g2 = (lane < SW_C && c2 >= 0 && c2 < cols) ? cl[ro + c2] : 0u;
+    // Right words: per row every lane fetches right column xq+l (g0) and, for l < 19, xq+64+l (g1).
+    // Column indices are clamped into the row: a clamped word only ever feeds an inadmissible
+    // (column, disparity) pair, which is masked out.
+    const unsigned c0 = (unsigned)min(max(xq + lane, 0), cols - 1);
+    const unsigned c1 = (unsigned)min(max(xq + 64 + (lane & 31), 0), cols - 1);
+    auto fetch = [&](int r, uint32_t &g0, uint32_t &g1) {
+        const uint32_t *rowp = cr + (long)(y_lo - 2 + r) * cols;   // uniform row base + per-lane column
+        g0 = rowp[c0];
+        g1 = rowp[c1];
     };
-    auto stash = [&](int r, uint32_t g0, uint32_t g1, uint32_t g2) {
-        uint32_t *s = stage[r & (SW_SLOTS - 1)];
-        s[lane] = g0;
-        if (lane < 32) s[64 + lane] = g1;
-        if (lane < SW_C) s[SW_LEFT_OFF + lane] = g2;
+    uint32_t *const st_w0 = &stage[0][lane], *const st_w1 = &stage[0][64 + (lane & 31)];
+    const uint32_t *const st_r = &stage[0][63 - lane];
+    auto stash = [&](int slot, uint32_t g0, uint32_t g1) {
+        st_w0[slot * SW_SLOT_WORDS] = g0;
+        st_w1[slot * SW_SLOT_WORDS] = g1;            // lanes l and l+32 store the same word
         __builtin_amdgcn_wave_barrier();            // the rows are read back by other lanes of this wavefront
     };
-    uint32_t g0, g1, g2;
-    fetch(0, g0, g1, g2);
-    stash(0, g0, g1, g2);
-    if (n_rows > 1) fetch(1, g0, g1, g2);
+    // Left words: 20 consecutive words of the row, the same for every lane -> scalar loads into SGPRs.
+    const uint32_t *lbase = cl + (xb - 2);
+    auto fetch_left = [&](int r, uint32_t (&w)[SW_C]) {
+        const uint32_t *lp = lbase + (long)(y_lo - 2 + r) * cols;
+#pragma unroll
+        for (int j = 0; j < SW_C; ++j) w[j] = lp[j];
+    };
 
+    // Software pipeline over rows: the global fetch of row r+3 and the scalar fetch of row r+1 are in
+    // flight while row r is processed.  Rows run in unconditional groups of ten (ring slot and sign are
+    // compile-time); rows past the end of the strip re-read the last census row and their winners are dropped.
+    const int last = n_rows - 1;
+    uint32_t g0, g1;
+    fetch(0, g0, g1);
+    stash(0, g0, g1);
+    fetch(min(1, last), g0, g1);
+    stash(1, g0, g1);
+    fetch(min(2, last), g0, g1);
+    uint32_t lw[SW_C];
+    fetch_left(0, lw);
+
+    // The scalar fetch of the next row's left words is issued right after the current row's words were
+    // consumed: scalar loads and LDS reads share one counter, so it must not sit in front of an LDS wait.
+    // Lane l holds column (l & 15) reduced over its 16-lane row; the LDS atomic merges the four rows.
 #define SVX_ROW(RR)                                                                                   \
-    if (r0 + RR < n_rows) {                                                                           \
+    {                                                                                                 \
         const int r = r0 + RR;                                                                        \
-        if (r + 1 < n_rows) stash(r + 1, g0, g1, g2);                                                 \
-        if (r + 2 < n_rows) fetch(r + 2, g0, g1, g2);                                                 \
-        const uint32_t zk = sweep_row<RR, MASKED>(st, stage[r & (SW_SLOTS - 1)], lane, (RR & 1) ? d_odd : d, xlim_base, dmax); \
-        if (r >= 4 && lane < SW_T) {     /* output row y_lo + r - 4; lanes 0..15 hold the 16 columns */ \
-            uint32_t *b = &best[r - 4][lane];                                                         \
-            *b = chunk == 0 ? zk : min(*b, zk);                                                       \
-        }                                                                                             \
+        sweep_row_accumulate(st, lw, st_r + (RR % SW_SLOTS) * SW_SLOT_WORDS);                         \
+        fetch_left(min(r + 1, last), lw);                                                             \
+        stash((RR + 2) % SW_SLOTS, g0, g1);                                                           \
+        fetch(min(r + 3, last), g0, g1);                                                              \
+        const uint32_t zk = sweep_row_reduce<RR, MASKED>(st, lane, (RR & 1) ? d_odd : d, xlim_base, dmax); \
+        if (r >= 4 && r < n_rows)                  /* output row y_lo + r - 4 */                      \
+            atomicMin(&best[r - 4][lane & 15], zk);                                                   \
     }
     for (int r0 = 0; r0 < n_rows; r0 += 10) {
         SVX_ROW(0) SVX_ROW(1) SVX_ROW(2) SVX_ROW(3) SVX_ROW(4)
@@ -226,9 +245,13 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
 #undef SVX_ROW
 }
 
-// grid: (x-blocks of 16 columns / 4, strips, frames); block: 256 threads = 4 independent wavefronts.
-__global__ __launch_bounds__(256) void dense_wta5x5_sweep_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
-                                                                 int rows, int cols, int max_disp, int strip_rows,
+// grid: (ceil(x-blocks / 4), strips, frames); block: 256 threads = 4 independent wavefronts.
+// x-block b covers output columns [xb, xb+16), xb = min(2 + 16 b, cols - 18): the last block is shifted
+// left so that it ends at column cols-3; the columns it shares with its neighbour get the same values
+// from both.  Requires cols >= 20.
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
+                                                                 int rows, int cols, int max_disp, int strip_rows, int n_xblocks,
                                                                  float *__restrict__ disp_all, int write_border) {
     __shared__ uint32_t lds_stage[4][SW_SLOTS][SW_SLOT_WORDS];
     __shared__ uint32_t lds_best[4][SW_MAX_STRIP][SW_T];
@@ -238,10 +261,13 @@ __global__ __launch_bounds__(256) void dense_wta5x5_sweep_kernel(const uint32_t 
     const uint32_t *cl = cl_all + (long)blockIdx.z * n;
     const uint32_t *cr = cr_all + (long)blockIdx.z * n;
     float *disp = disp_all + (long)blockIdx.z * n;
-    const int xb = (blockIdx.x * 4 + wave) * SW_T;          // first output column of this wavefront
-    if (xb >= cols) return;
-    const int ys = blockIdx.y * strip_rows;                 // first output row of the strip
-    const int y_lo = max(ys, 2), y_hi = min(ys + strip_rows, rows - 2);   // output rows [y_lo, y_hi)
+    const int xblock = blockIdx.x * 4 + wave;
+    if (xblock >= n_xblocks) return;
+    const int xb = min(2 + xblock * SW_T, cols - 2 - SW_T);    // first output column of this wavefront
+    // strip k produces output rows [2 + k*strip_rows, 2 + (k+1)*strip_rows) clipped to rows-2; for the
+    // frame border the first strip also owns rows 0,1 and the last one rows rows-2, rows-1
+    const int y_lo = 2 + blockIdx.y * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
+    const int ys = blockIdx.y == 0 ? 0 : y_lo, y_end = blockIdx.y == gridDim.y - 1 ? rows : y_hi;
     uint32_t (*stage)[SW_SLOT_WORDS] = lds_stage[wave];
     uint32_t (*best)[SW_T] = lds_best[wave];
 
@@ -249,6 +275,8 @@ __global__ __launch_bounds__(256) void dense_wta5x5_sweep_kernel(const uint32_t 
         const int n_out = y_hi - y_lo;
         const int n_rows = n_out + 4;                       // census rows y_lo-2 .. y_hi+1
         const int n_chunks = (max_disp + 63) >> 6;
+        for (int i = lane; i < n_out * SW_T; i += 64) best[0][i] = 0xffffffffu;
+        __builtin_amdgcn_wave_barrier();
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
             const int dbase = chunk << 6;
             // no disparity of this chunk is admissible for any column of the block
@@ -260,21 +288,17 @@ __global__ __launch_bounds__(256) void dense_wta5x5_sweep_kernel(const uint32_t 
         }
         __builtin_amdgcn_wave_barrier();
         // write-out: 4 rows x 16 columns per pass
-        for (int o = (lane >> 4); o < n_out; o += 4) {
-            const int x = xb + (lane & 15), y = y_lo + o;
-            if (x < cols) {
-                float v = 0.0f;
-                const bool inner = x >= 2 && x < cols - 2;
-                if (inner && x >= 5) v = (float)(best[o][lane & 15] & SW_DMASK);
-                if (inner || write_border) disp[(long)y * cols + x] = v;
-            }
-        }
+        for (int o = (lane >> 4); o < n_out; o += 4)
+            disp[(long)(y_lo + o) * cols + xb + (lane & 15)] = (float)(best[o][lane & 15] & SW_DMASK);
     }
     if (write_border) {
-        // rows of this strip outside [2, rows-2)
-        for (int y = ys + (lane >> 4); y < min(ys + strip_rows, rows); y += 4) {
-            const int x = xb + (lane & 15);
-            if ((y < 2 || y >= rows - 2) && x < cols) disp[(long)y * cols + x] = 0.0f;
+        // the frame border is 0: rows outside [2, rows-2) over this block's columns, and the two
+        // border columns on either side (written by the first and the last block)
+        for (int y = ys + (lane >> 4); y < y_end; y += 4)
+            if (y < 2 || y >= rows - 2) disp[(long)y * cols + xb + (lane & 15)] = 0.0f;
+        if (xblock == 0 || xblock == n_xblocks - 1) {
+            const int xc = (xblock == 0 ? 0 : cols - 2) + (lane & 1);
+            for (int y = ys + (lane >> 1); y < y_end; y += 32) disp[(long)y * cols + xc] = 0.0f;
         }
     }
 }
@@ -289,17 +313,23 @@ static int dense_args_ok(svx_ctx *ctx, const void *a, const void *b, const void 
 
 static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
                         float *disparity, int write_border) {
-    if (max_disp > SW_DMASK + 1) {
+    if (max_disp > SW_DMASK + 1 || cols < SW_T + 4 || rows < 5) {
         dim3 grid(svx_cdiv(cols, 64), svx_cdiv(rows, 4), n_frames);
         dense_wta5x5_plain_kernel<<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity, write_border);
         SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_plain_kernel");
         return SVX_OK;
     }
-    // strips: as tall as the LDS best-key store allows, evened out over the image
-    const int n_strips = (rows + SW_MAX_STRIP - 1) / SW_MAX_STRIP;
-    const int strip_rows = (rows + n_strips - 1) / n_strips;
-    dim3 grid(svx_cdiv(cols, SW_T * 4), svx_cdiv(rows, strip_rows), n_frames);
-    dense_wta5x5_sweep_kernel<<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border);
+    // strips of SW_MAX_STRIP output rows from row 2 on: strip + 4 halo rows is a whole number of 10-row groups
+    const int strip_rows = SW_MAX_STRIP;
+    const int n_strips = (rows - 4 + strip_rows - 1) / strip_rows;
+    const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
+    dim3 grid(svx_cdiv(n_xblocks, 4), n_strips, n_frames);
+    // Tuning knob: SVX_SWEEP_OCC=2 selects the build that may use up to 256 VGPRs (2 wavefronts per SIMD).
+    static const int occ = [] { const char *e = getenv("SVX_SWEEP_OCC"); return e ? atoi(e) : 3; }();
+    if (occ == 2)
+        dense_wta5x5_sweep_kernel<2><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border);
+    else
+        dense_wta5x5_sweep_kernel<3><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border);
     SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_sweep_kernel");
     return SVX_OK;
 }
