@@ -76,7 +76,7 @@ def main():
     import torch
     import torch.distributed as dist
     import stereovision_amd as S
-    from stereovision_amd import synth
+    from stereovision_amd import sharding, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -95,17 +95,15 @@ def main():
     cols, rows, D, F = 16 * (FULL_W // 16), 16 * (FULL_H // 16), args.max_disp, args.frames
     ctx = S.Context(local_rank)
 
-    # synthetic batch of this rank: seeds rank*F .. rank*F+F-1 (8 distinct pairs, tiled, keeps set-up short)
+    # synthetic batch of this rank: frames rank*F .. rank*F+F-1 (8 distinct pairs, tiled, keeps set-up short)
     n_gen = min(F, 8)
-    ls, rs = synth.stereo_batch(rows, cols, D, n_gen, seed0=rank * F)
+    ls, rs = synth.stereo_batch(rows, cols, D, n_gen, seed0=sharding.frame_seeds(rank, F)[0])
     reps = (F + n_gen - 1) // n_gen
     left = torch.from_numpy(np.tile(ls, (reps, 1, 1))[:F].copy()).to(dev)
     right = torch.from_numpy(np.tile(rs, (reps, 1, 1))[:F].copy()).to(dev)
     disp = torch.empty((F, rows, cols), dtype=torch.float32, device=dev)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = sharding.barrier
 
     def step():
         ctx.dense_census_wta(left, right, D, out=disp)
@@ -120,25 +118,20 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
 
     pixdisp_per_frame = rows * cols * D
-    value = pixdisp_per_frame * F * world * args.steps / elapsed / 1e6
+    value = sharding.throughput_mpixdisp(rows, cols, D, F, world, args.steps, elapsed)
     frames_per_s = F * world * args.steps / elapsed
 
     # evaluation-only gather of the disparity maps to GPU0 over RCCL/xGMI (outside the timed region)
     gather_ms = None
     if world > 1 and not args.no_gather:
         try:
-            bufs = [torch.empty_like(disp) for _ in range(world)] if rank == 0 else None
             torch.cuda.synchronize(dev)
             barrier()
             g0 = time.perf_counter()
-            dist.gather(disp, bufs, dst=0)
+            sharding.gather_to_rank0(disp)
             torch.cuda.synchronize(dev)
             barrier()
             gather_ms = (time.perf_counter() - g0) * 1e3
@@ -167,6 +160,13 @@ def main():
         except Exception:
             measured_peak = None
         achieved = valu_ops / (k_ms * 1e-3) / 1e12
+        traffic = None   # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if tj["kernel"] == S.DOMINANT_KERNEL and F == 64 and D == 128:
+                traffic = (tj["fetch_size_kb"] + tj["write_size_kb"]) * 1024.0
+        except Exception:
+            traffic = None
         roofline = {
             "bound": "valu",
             "kernel": S.DOMINANT_KERNEL,
@@ -174,7 +174,7 @@ def main():
             "peak": round(VALU_PEAK_TLOPS, 2),
             "unit": "Tlane-op/s",
             "frac": round(achieved / VALU_PEAK_TLOPS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "kernel_ms": round(k_ms, 4),
             "algorithmic_ops_per_launch": valu_ops,
             "measured_xor_bcnt_peak": None if measured_peak is None else round(measured_peak, 2),
@@ -189,7 +189,7 @@ def main():
         # ---- CPU baseline (oracle port, 1 thread) + parity spot check on the same frame ----
         cpu = None
         parity = "not checked"
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:
             cpu, want, nrows = cpu_baseline(ls[0], rs[0], D, args.cpu_frames)
             got = disp[0].cpu().numpy()
             same = bool(np.array_equal(got[2:2 + nrows], want[2:2 + nrows]))

@@ -1,0 +1,64 @@
+"""Multi-process (gloo, world_size 2, CPU) test of the frame-sharding logic bench.py uses on N GPUs:
+every rank owns its own batch (weak scaling), the timed region is bracketed by barriers, the step time
+is the MAX over ranks, the throughput is the units of all ranks over that time, and the evaluation
+gather brings every rank's disparity maps to rank 0.  The compute itself is replaced by the CPU oracle
+here (this is a test of the host logic, not of the kernels)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    from stereovision_amd import sharding, synth
+
+    rows, cols, D, frames_per_rank = 24, 64, 16, 2
+    seeds = sharding.frame_seeds(rank, frames_per_rank)
+    assert seeds == list(range(rank * frames_per_rank, (rank + 1) * frames_per_rank))
+    ls, rs = synth.stereo_batch(rows, cols, D, frames_per_rank, seed0=seeds[0])
+    disp = np.stack([O.dense_wta5x5(O.census5x5(O.u8_to_s8(l)), O.census5x5(O.u8_to_s8(r)), D) for l, r in zip(ls, rs)])
+    # each rank reports a different local time; the job time is the max
+    local_t = 0.5 + 0.25 * rank
+    job_t = sharding.max_over_ranks(local_t, torch.device("cpu"))
+    assert abs(job_t - (0.5 + 0.25 * (world - 1))) < 1e-12
+    value = sharding.throughput_mpixdisp(rows, cols, D, frames_per_rank, world, steps=3, seconds=job_t)
+    assert abs(value - rows * cols * D * frames_per_rank * world * 3 / job_t / 1e6) < 1e-9
+    gathered = sharding.gather_to_rank0(torch.from_numpy(disp))
+    if rank == 0:
+        assert len(gathered) == world
+        for r in range(world):
+            l2, r2 = synth.stereo_batch(rows, cols, D, frames_per_rank, seed0=r * frames_per_rank)
+            want = np.stack([O.dense_wta5x5(O.census5x5(O.u8_to_s8(a)), O.census5x5(O.u8_to_s8(b)), D) for a, b in zip(l2, r2)])
+            assert np.array_equal(gathered[r].numpy(), want)
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    else:
+        assert gathered is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()

@@ -347,3 +347,15 @@ def test_argument_errors(ctx):
         ctx.dense_census_wta(img, img, 0)
     with pytest.raises(S.SvxError):
         ctx.dense_census_wta(img, dev(np.zeros((8, 32), np.uint8)), 8)
+
+
+# ------------------------------------------------------------------ C++ mirror of the reference interface
+def test_cpp_reference_api_program():
+    """tests/cpp/test_reference_api.cpp drives stereovision_amd/cpp/svx_reference_api.hpp (reference class and
+    function names) and checks the reference's known-answer values; built by __graft_entry__.build()."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "test_reference_api")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "reference-api checks passed" in p.stdout

@@ -141,3 +141,27 @@ def test_sparse_match_constant_disparity():
         lx, ly = lf[ol[i]]
         rx, ry = rf[orr[i]]
         assert ly == ry and lx - rx == d and oc[i] == 0
+
+
+def test_plane_fit_against_reference_build():
+    """The reference's own CramerTheorem.cpp + Matrix.cpp (compiled from where they lie into oracle/_ref)."""
+    so = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libref_cramer.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    ref = C.CDLL(so)
+    ref.ref_plane_fit.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(21)
+    cases = []
+    for _ in range(3000):
+        xy = rng.integers(0, 1300, size=(3, 2)).astype(np.float64)
+        d = rng.uniform(0, 128, size=(3, 1)).astype(np.float32).astype(np.float64)
+        cases.append(np.concatenate([xy, d], 1))
+    cases.append(np.array([[5, 5, 1.0], [10, 10, 2.0], [20, 20, 3.0]]))      # collinear -> singular
+    cases.append(np.array([[3, 3, 1.0], [3, 3, 1.0], [9, 1, 4.0]]))          # repeated vertex
+    cases.append(np.array([[0, 0, 7.0], [1, 0, 7.0], [0, 1, 7.0]]))          # constant plane
+    for xyd in cases:
+        xyd = np.ascontiguousarray(xyd)
+        want = np.zeros(3, np.float32)
+        ref.ref_plane_fit(xyd.ctypes.data, want.ctypes.data)
+        got = O.plane_fit(xyd)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (xyd, got, want)
