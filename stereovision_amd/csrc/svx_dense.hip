@@ -245,7 +245,9 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
 #undef SVX_ROW
 }
 
-// grid: (ceil(x-blocks / 4), strips, frames); block: 256 threads = 4 independent wavefronts.
+// grid: (ceil(x-blocks / 2), strips, frames); block: 256 threads = 4 wavefronts = 2 x-blocks x 2 chunk
+// parities: wavefronts 2k and 2k+1 sweep the even and the odd 64-disparity chunks of x-block k and merge
+// their winners in one shared best-key array with LDS atomics (two barriers per block, none in the sweep).
 // x-block b covers output columns [xb, xb+16), xb = min(2 + 16 b, cols - 18): the last block is shifted
 // left so that it ends at column cols-3; the columns it shares with its neighbour get the same values
 // from both.  Requires cols >= 20.
@@ -254,30 +256,32 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
                                                                  int rows, int cols, int max_disp, int strip_rows, int n_xblocks,
                                                                  float *__restrict__ disp_all, int write_border) {
     __shared__ uint32_t lds_stage[4][SW_SLOTS][SW_SLOT_WORDS];
-    __shared__ uint32_t lds_best[4][SW_MAX_STRIP][SW_T];
+    __shared__ uint32_t lds_best[2][SW_MAX_STRIP][SW_T];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave >> 1, parity = wave & 1;
     const long n = (long)rows * cols;
     const uint32_t *cl = cl_all + (long)blockIdx.z * n;
     const uint32_t *cr = cr_all + (long)blockIdx.z * n;
     float *disp = disp_all + (long)blockIdx.z * n;
-    const int xblock = blockIdx.x * 4 + wave;
-    if (xblock >= n_xblocks) return;
+    const int xblock = blockIdx.x * 2 + pair;
+    const bool active = xblock < n_xblocks;
     const int xb = min(2 + xblock * SW_T, cols - 2 - SW_T);    // first output column of this wavefront
     // strip k produces output rows [2 + k*strip_rows, 2 + (k+1)*strip_rows) clipped to rows-2; for the
     // frame border the first strip also owns rows 0,1 and the last one rows rows-2, rows-1
     const int y_lo = 2 + blockIdx.y * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
     const int ys = blockIdx.y == 0 ? 0 : y_lo, y_end = blockIdx.y == gridDim.y - 1 ? rows : y_hi;
     uint32_t (*stage)[SW_SLOT_WORDS] = lds_stage[wave];
-    uint32_t (*best)[SW_T] = lds_best[wave];
+    uint32_t (*best)[SW_T] = lds_best[pair];
+    const int n_out = y_hi - y_lo;                          // >= 1 by construction of the grid
+    const int half = parity * 64 + lane;                    // 0..127 over the two wavefronts of the pair
 
-    if (y_lo < y_hi) {
-        const int n_out = y_hi - y_lo;
+    for (int i = half; i < n_out * SW_T; i += 128) best[0][i] = 0xffffffffu;
+    __syncthreads();
+    if (active) {
         const int n_rows = n_out + 4;                       // census rows y_lo-2 .. y_hi+1
         const int n_chunks = (max_disp + 63) >> 6;
-        for (int i = lane; i < n_out * SW_T; i += 64) best[0][i] = 0xffffffffu;
-        __builtin_amdgcn_wave_barrier();
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        for (int chunk = parity; chunk < n_chunks; chunk += 2) {
             const int dbase = chunk << 6;
             // no disparity of this chunk is admissible for any column of the block
             if (chunk > 0 && dbase > xb + SW_T - 1 - 5) break;
@@ -286,19 +290,20 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
             if (masked) sweep_chunk<true>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
             else sweep_chunk<false>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
         }
-        __builtin_amdgcn_wave_barrier();
-        // write-out: 4 rows x 16 columns per pass
-        for (int o = (lane >> 4); o < n_out; o += 4)
-            disp[(long)(y_lo + o) * cols + xb + (lane & 15)] = (float)(best[o][lane & 15] & SW_DMASK);
     }
+    __syncthreads();
+    if (!active) return;
+    // write-out: 8 rows x 16 columns per pass over the pair
+    for (int o = (half >> 4); o < n_out; o += 8)
+        disp[(long)(y_lo + o) * cols + xb + (lane & 15)] = (float)(best[o][lane & 15] & SW_DMASK);
     if (write_border) {
         // the frame border is 0: rows outside [2, rows-2) over this block's columns, and the two
         // border columns on either side (written by the first and the last block)
-        for (int y = ys + (lane >> 4); y < y_end; y += 4)
+        for (int y = ys + (half >> 4); y < y_end; y += 8)
             if (y < 2 || y >= rows - 2) disp[(long)y * cols + xb + (lane & 15)] = 0.0f;
         if (xblock == 0 || xblock == n_xblocks - 1) {
             const int xc = (xblock == 0 ? 0 : cols - 2) + (lane & 1);
-            for (int y = ys + (lane >> 1); y < y_end; y += 32) disp[(long)y * cols + xc] = 0.0f;
+            for (int y = ys + (half >> 1); y < y_end; y += 64) disp[(long)y * cols + xc] = 0.0f;
         }
     }
 }
@@ -323,7 +328,7 @@ static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     const int strip_rows = SW_MAX_STRIP;
     const int n_strips = (rows - 4 + strip_rows - 1) / strip_rows;
     const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
-    dim3 grid(svx_cdiv(n_xblocks, 4), n_strips, n_frames);
+    dim3 grid(svx_cdiv(n_xblocks, 2), n_strips, n_frames);
     // Tuning knob: SVX_SWEEP_OCC=2 selects the build that may use up to 256 VGPRs (2 wavefronts per SIMD).
     static const int occ = [] { const char *e = getenv("SVX_SWEEP_OCC"); return e ? atoi(e) : 3; }();
     if (occ == 2)

@@ -49,6 +49,9 @@
 #define OP_MADI24(s, a) "v_mad_i32_i24 %" #s ", %" #a ", -1, %" #s "\n\t"
 #define OP_CMPGT(s, a) "v_cmp_gt_i32_e32 vcc, %" #a ", %" #s "\n\t"
 #define OP_ADDC(s, a) "v_addc_co_u32_e32 %" #s ", vcc, %" #s ", %" #s ", vcc\n\t"
+#define OP_XORIP(s, a) "v_xor_b32_e32 %" #a ", %32, %" #a "\n\t"
+#define OP_BCNTONLY(s, a) "v_bcnt_u32_b32 %" #s ", %" #a ", %" #s "\n\t"
+#define OP_SUBIP(s, a) "v_sub_u32_e32 %" #a ", %" #a ", %" #s "\n\t"
 #define OP_XORBCNT(s, a) "v_xor_b32_e32 %" #a ", %" #a ", %" #s "\n\tv_bcnt_u32_b32 %" #s ", %" #a ", %" #s "\n\t"
 
 template <int MODE>
@@ -71,6 +74,9 @@ __global__ __launch_bounds__(256) void k(uint32_t *sink, int iters) {
             else if (MODE == 24) BODY(OP_MOV); else if (MODE == 25) BODY(OP_ALIGNBIT); else if (MODE == 26) BODY(OP_PKSUB);
             else if (MODE == 27) BODY(OP_MADI24); else if (MODE == 28) BODY(OP_CMPGT); else if (MODE == 29) BODY(OP_ADDC);
             else if (MODE == 30) BODY(OP_XORBCNT);
+            else if (MODE == 31) { BODY(OP_XORIP); BODY(OP_BCNTONLY); }
+            else if (MODE == 32) { BODY(OP_SUBIP); BODY(OP_ADD3); }
+            else if (MODE == 33) { BODY(OP_XORIP); BODY(OP_XORIP); BODY(OP_BCNTONLY); BODY(OP_BCNTONLY); }
         }
         k += 0x01010101u;
     }
@@ -96,7 +102,7 @@ int main() {
         {"v_cndmask_b32_e32", k<16>, 16}, {"v_min3_u32", k<17>, 16}, {"v_sad_u32", k<18>, 16}, {"v_xad_u32", k<19>, 16},
         {"v_add_u32_sdwa", k<20>, 16}, {"v_and_b32_e32", k<21>, 16}, {"v_lshrrev_b32_e32", k<22>, 16}, {"v_bfe_u32", k<23>, 16},
         {"v_mov_b32_e32", k<24>, 16}, {"v_alignbit_b32", k<25>, 16}, {"v_pk_sub_i16", k<26>, 16}, {"v_mad_i32_i24", k<27>, 16},
-        {"v_cmp_gt_i32_e32", k<28>, 16}, {"v_addc_co_u32_e32", k<29>, 16}, {"xor_e32+bcnt pair", k<30>, 32},
+        {"v_cmp_gt_i32_e32", k<28>, 16}, {"v_addc_co_u32_e32", k<29>, 16}, {"xor_e32+bcnt pair", k<30>, 32}, {"16 xor_e32(sgpr) ; 16 bcnt", k<31>, 32}, {"16 sub_e32 ; 16 add3", k<32>, 32}, {"32 xor ; 32 bcnt", k<33>, 64},
     };
     const int iters = 2000;
     hipEvent_t e0, e1;
