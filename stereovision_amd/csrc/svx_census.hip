@@ -55,6 +55,53 @@ constexpr int CT_W = 256;            // tile width in pixels (one wave spans it:
 constexpr int CT_H = 16;             // tile height: 4 waves x 4 rows
 constexpr int CT_LROW = CT_W / 4 + 2;  // dwords per staged row: columns x0-4 .. x0+CT_W+3
 
+// One comparison bit: word = 2*word + (centre > neighbour), both operands picked as unsigned bytes straight
+// out of packed registers by SDWA (no extraction instructions).  Pixels are kept in the UNSIGNED domain
+// (signed input is biased by 0x80 at staging), where the reference's signed compare is an unsigned one.
+#define CENSUS_BIT(WORD, CREG, CB, NREG, NB)                                                                   \
+    asm("v_cmp_gt_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #CB " src1_sel:BYTE_" #NB "\n\t"                         \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc"                                                               \
+        : "+v"(WORD) : "v"(CREG), "v"(NREG) : "vcc")
+
+// The 24 bits of pixel I (0..3) of a 4-pixel group, most significant first (idx = 0..24 without the centre).
+// Row windows: lo = columns x-2..x+1, hi = columns x+2..x+5; neighbour (dy,dx) of pixel I is window byte
+// 2+I+dx of row dy+2, the centre is window byte 2+I of row 2.
+#define CENSUS_ROW5(WORD, CREG, CB, LO, HI, B0, R0, B1, R1, B2, R2, B3, R3, B4, R4)                             \
+    CENSUS_BIT(WORD, CREG, CB, R0, B0); CENSUS_BIT(WORD, CREG, CB, R1, B1); CENSUS_BIT(WORD, CREG, CB, R2, B2); \
+    CENSUS_BIT(WORD, CREG, CB, R3, B3); CENSUS_BIT(WORD, CREG, CB, R4, B4)
+#define CENSUS_ROW4(WORD, CREG, CB, B0, R0, B1, R1, B3, R3, B4, R4)                                             \
+    CENSUS_BIT(WORD, CREG, CB, R0, B0); CENSUS_BIT(WORD, CREG, CB, R1, B1);                                     \
+    CENSUS_BIT(WORD, CREG, CB, R3, B3); CENSUS_BIT(WORD, CREG, CB, R4, B4)
+
+// pixel 0: window bytes 0..4 = lo.0 lo.1 lo.2 lo.3 hi.0, centre lo.2
+#define CENSUS_PX0(WORD, L, H)                                                                                 \
+    CENSUS_ROW5(WORD, L[2], 2, , , 0, L[0], 1, L[0], 2, L[0], 3, L[0], 0, H[0]);                                \
+    CENSUS_ROW5(WORD, L[2], 2, , , 0, L[1], 1, L[1], 2, L[1], 3, L[1], 0, H[1]);                                \
+    CENSUS_ROW4(WORD, L[2], 2, 0, L[2], 1, L[2], 3, L[2], 0, H[2]);                                             \
+    CENSUS_ROW5(WORD, L[2], 2, , , 0, L[3], 1, L[3], 2, L[3], 3, L[3], 0, H[3]);                                \
+    CENSUS_ROW5(WORD, L[2], 2, , , 0, L[4], 1, L[4], 2, L[4], 3, L[4], 0, H[4])
+// pixel 1: window bytes 1..5 = lo.1 lo.2 lo.3 hi.0 hi.1, centre lo.3
+#define CENSUS_PX1(WORD, L, H)                                                                                 \
+    CENSUS_ROW5(WORD, L[2], 3, , , 1, L[0], 2, L[0], 3, L[0], 0, H[0], 1, H[0]);                                \
+    CENSUS_ROW5(WORD, L[2], 3, , , 1, L[1], 2, L[1], 3, L[1], 0, H[1], 1, H[1]);                                \
+    CENSUS_ROW4(WORD, L[2], 3, 1, L[2], 2, L[2], 0, H[2], 1, H[2]);                                             \
+    CENSUS_ROW5(WORD, L[2], 3, , , 1, L[3], 2, L[3], 3, L[3], 0, H[3], 1, H[3]);                                \
+    CENSUS_ROW5(WORD, L[2], 3, , , 1, L[4], 2, L[4], 3, L[4], 0, H[4], 1, H[4])
+// pixel 2: window bytes 2..6 = lo.2 lo.3 hi.0 hi.1 hi.2, centre hi.0
+#define CENSUS_PX2(WORD, L, H)                                                                                 \
+    CENSUS_ROW5(WORD, H[2], 0, , , 2, L[0], 3, L[0], 0, H[0], 1, H[0], 2, H[0]);                                \
+    CENSUS_ROW5(WORD, H[2], 0, , , 2, L[1], 3, L[1], 0, H[1], 1, H[1], 2, H[1]);                                \
+    CENSUS_ROW4(WORD, H[2], 0, 2, L[2], 3, L[2], 1, H[2], 2, H[2]);                                             \
+    CENSUS_ROW5(WORD, H[2], 0, , , 2, L[3], 3, L[3], 0, H[3], 1, H[3], 2, H[3]);                                \
+    CENSUS_ROW5(WORD, H[2], 0, , , 2, L[4], 3, L[4], 0, H[4], 1, H[4], 2, H[4])
+// pixel 3: window bytes 3..7 = lo.3 hi.0 hi.1 hi.2 hi.3, centre hi.1
+#define CENSUS_PX3(WORD, L, H)                                                                                 \
+    CENSUS_ROW5(WORD, H[2], 1, , , 3, L[0], 0, H[0], 1, H[0], 2, H[0], 3, H[0]);                                \
+    CENSUS_ROW5(WORD, H[2], 1, , , 3, L[1], 0, H[1], 1, H[1], 2, H[1], 3, H[1]);                                \
+    CENSUS_ROW4(WORD, H[2], 1, 3, L[2], 0, H[2], 2, H[2], 3, H[2]);                                             \
+    CENSUS_ROW5(WORD, H[2], 1, , , 3, L[3], 0, H[3], 1, H[3], 2, H[3], 3, H[3]);                                \
+    CENSUS_ROW5(WORD, H[2], 1, , , 3, L[4], 0, H[4], 1, H[4], 2, H[4], 3, H[4])
+
 // Requires cols % 4 == 0 and 4-byte aligned frame bases, so that every staged
 // dword lies entirely inside or entirely outside the frame.
 template <bool IS_U8>
@@ -67,13 +114,14 @@ __global__ __launch_bounds__(256) void census5x5_tile_kernel(const uint8_t *__re
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
     const int tid = threadIdx.x;
 
+    // staging in the unsigned domain; outside the frame reads the signed value 0, i.e. 0x80 unsigned
     for (int i = tid; i < (CT_H + 4) * CT_LROW; i += 256) {
         const int r = i / CT_LROW, k = i - r * CT_LROW;
         const long flat = (long)(y0 - 2 + r) * cols + (x0 - 4 + 4 * k);
-        uint32_t v = 0;
+        uint32_t v = 0x80808080u;
         if (flat >= 0 && flat < n) {
             v = *reinterpret_cast<const uint32_t *>(in + flat);
-            if (IS_U8) v ^= 0x80808080u;
+            if (!IS_U8) v ^= 0x80808080u;
         }
         tile[i] = v;
     }
@@ -85,45 +133,32 @@ __global__ __launch_bounds__(256) void census5x5_tile_kernel(const uint8_t *__re
     const bool generic = (flags & 15) == SVX_CENSUS_GENERIC25;
     const bool zero_rest = (flags & SVX_CENSUS_ZERO_REST) != 0;
 
-    // 64-bit window of row r covering columns x-2 .. x+5.
-    auto window = [&](int r) -> uint64_t {
-        const uint32_t *p = tile + r * CT_LROW + lane;
-        const uint32_t a = p[0], b = p[1], c = p[2];
-        const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, 2);
-        const uint32_t hi = __builtin_amdgcn_alignbyte(c, b, 2);
-        return ((uint64_t)hi << 32) | lo;
-    };
-
-    uint64_t w[5];
+    // lo/hi windows of the 8 staged rows this lane needs: columns x-2..x+1 and x+2..x+5
+    uint32_t lo[8], hi[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w[r + 1] = window(wave * 4 + r);
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t *p = tile + (wave * 4 + r) * CT_LROW + lane;
+        const uint32_t a = p[0], b = p[1], c = p[2];
+        lo[r] = __builtin_amdgcn_alignbyte(b, a, 2);
+        hi[r] = __builtin_amdgcn_alignbyte(c, b, 2);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int y = y0 + wave * 4 + j;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = w[r + 1];
-        w[4] = window(wave * 4 + j + 4);
         if (y >= rows) break;
-        uint32_t res[4];
+        uint32_t res[4] = {0u, 0u, 0u, 0u};
         if (y >= 2 && y < rows - 2) {
+            const uint32_t *L = lo + j, *H = hi + j;
+            CENSUS_PX0(res[0], L, H);
+            CENSUS_PX1(res[1], L, H);
+            CENSUS_PX2(res[2], L, H);
+            CENSUS_PX3(res[3], L, H);
+            if (generic) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = (int8_t)(w[2] >> (8 * (2 + i)));
-                uint32_t word = 0;
-#pragma unroll
-                for (int dy = -2; dy <= 2; ++dy)
-#pragma unroll
-                    for (int dx = -2; dx <= 2; ++dx) {
-                        if (dy == 0 && dx == 0) continue;
-                        const int nb = (int8_t)(w[dy + 2] >> (8 * (2 + i + dx)));
-                        word |= (uint32_t)(c > nb) << census_bit24(dy, dx);
-                    }
-                res[i] = generic ? census24_to_25(word) : word;
+                for (int i = 0; i < 4; ++i) res[i] = census24_to_25(res[i]);
             }
             uint32_t *o = out + (long)y * cols + x;
-            if (!generic) {
-                *reinterpret_cast<uint4 *>(o) = make_uint4(res[0], res[1], res[2], res[3]);
-            } else if (x >= 2 && x + 3 < cols - 2) {
+            if (!generic || (x >= 2 && x + 3 < cols - 2)) {
                 *reinterpret_cast<uint4 *>(o) = make_uint4(res[0], res[1], res[2], res[3]);
             } else {
 #pragma unroll
