@@ -84,6 +84,19 @@ enum { SVX_CENSUS_SSE24 = 0, SVX_CENSUS_GENERIC25 = 1, SVX_CENSUS_ZERO_REST = 16
 int svx_census5x5_s8(svx_ctx *ctx, const int8_t *in, uint32_t *out, int rows, int cols, int n_frames, int flags);
 int svx_census5x5_u8(svx_ctx *ctx, const uint8_t *in, uint32_t *out, int rows, int cols, int n_frames, int flags);
 
+/* ---- a14: generic N x N census -------------------------------------------
+ * Replaces CensusTransform::CensusTransform / computeCensus, denseCensusStereo/
+ * CensusTransform.h, CensusTransform.cpp:9-67: size is made odd, every pixel
+ * gets svx_census_nxn_words(size) = m*m/32 + 1 words (pixel-major), bit j*m+i
+ * set when neighbour >= centre, all-zero within m/2 of the border, and the
+ * reference's skip test (window index compared with the image coordinate,
+ * CensusTransform.cpp:47) reproduced.  svx_census_nxn_u8 first narrows the
+ * unsigned pixels with saturation to 127, as the reference's callers do
+ * implicitly (denseCensusStereo.cpp:307-308). */
+int svx_census_nxn_words(int size);
+int svx_census_nxn_s8(svx_ctx *ctx, const int8_t *in, int rows, int cols, int n_frames, int size, uint32_t *out);
+int svx_census_nxn_u8(svx_ctx *ctx, const uint8_t *in, int rows, int cols, int n_frames, int size, uint32_t *out);
+
 /* ---- a4: census window cost ---------------------------------------------
  * Replaces CensusWindow<5>::setReferencePoint + match, sparsestereo/
  * censuswindow.h:46-49, :96-107.  For pair p: cost[p] = window Hamming cost of
@@ -127,6 +140,22 @@ int svx_dense_census_wta_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *ri
 int svx_epipolar_match_batch(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right,
                              int rows, int cols, int census_size, int cost_aggr_window_size,
                              const int32_t *pts_xy, int n_pts, int max_disp, float *out_disp, int8_t *out_cost);
+
+/* ---- a13: support resampling (device part) ---------------------------------
+ * Replaces the loop of supportResampling, highPerfStereoLib.h:216-222,
+ * highPerfStereoLib.cpp:141-175, without the mesh: for cell c (row-major) slot
+ * 2c is its invalid match re-matched over the full range (a9) and accepted when
+ * the winner's single-pixel cost is < t_low; slot 2c+1 is its confident
+ * support.  Accepted slots get out_valid = 1, their disparity is written into
+ * `disparities`, and (out_xy[2s], out_xy[2s+1], out_d[s]) is the point to insert
+ * into the mesh; the reference's insertion order is slot order.  Grid arrays
+ * are those returned by svx_refine. */
+int svx_support_resampling(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                           int census_size, int cost_aggr_window_size, int grid_w, int grid_h,
+                           const int32_t *conf_x, const int32_t *conf_y, const float *conf_d, const int8_t *conf_c,
+                           const int32_t *inv_x, const int32_t *inv_y, const int8_t *inv_c,
+                           int t_low, int t_high, int max_disp, float *disparities,
+                           int32_t *out_xy, float *out_d, uint8_t *out_valid);
 
 /* ---- a10: cost of the plane prior ----------------------------------------
  * Replaces costEvaluation, highPerfStereoLib.h:196-200, .cpp:20-41.

@@ -450,3 +450,76 @@ ORC_API void orc_plane_prior_raster(const int32_t *tri_xy /* ntri*6 */, const fl
                 }
             }
 }
+
+/* ----------------------------------------------------------------- a13 --
+ * highPerfStereo/highPerfStereoLib.cpp:141-175  supportResampling, without the
+ * mesh: cells are visited row-major; an invalid match with cost > tHigh is
+ * re-matched over the full range (a9) and becomes a support point when the
+ * winner's single-pixel cost is < tLow; then the cell's confident support (cost
+ * < tLow) becomes one.  Each new support writes its disparity into the prior
+ * map and is appended to the output list (the order in which the reference
+ * inserts them into the mesh).  Returns the number of points.  No known-answer
+ * value of the reference covers this routine: parity unpinned beyond a9. */
+ORC_API int orc_support_resampling(const uint32_t *cl, const uint32_t *cr, int rows, int cols,
+                                   int censusSize, int costAggrWindowSize, int gridW, int gridH,
+                                   const int32_t *conf_x, const int32_t *conf_y, const float *conf_d, const int8_t *conf_c,
+                                   const int32_t *inv_x, const int32_t *inv_y, const int8_t *inv_c,
+                                   int tLow, int tHigh, int maxDisp, float *disparities,
+                                   int32_t *out_xy, float *out_d) {
+    int n = 0;
+    const int8_t tl = (int8_t)tLow, th = (int8_t)tHigh;
+    for (int j = 0; j < gridH; ++j)
+        for (int i = 0; i < gridW; ++i) {
+            const int c = j * gridW + i;
+            if (inv_c[c] > th) {
+                float d; int8_t cost;
+                orc_epipolar_match(cl, cr, rows, cols, censusSize, costAggrWindowSize, inv_x[c], inv_y[c], maxDisp, &d, &cost);
+                if (cost < tl) {
+                    disparities[(long)inv_y[c] * cols + inv_x[c]] = d;
+                    out_xy[2 * n] = inv_x[c]; out_xy[2 * n + 1] = inv_y[c]; out_d[n] = d; ++n;
+                }
+            }
+            if (conf_c[c] < tl) {
+                disparities[(long)conf_y[c] * cols + conf_x[c]] = conf_d[c];
+                out_xy[2 * n] = conf_x[c]; out_xy[2 * n + 1] = conf_y[c]; out_d[n] = conf_d[c]; ++n;
+            }
+        }
+    return n;
+}
+
+/* ----------------------------------------------------------------- a14 --
+ * denseCensusStereo/CensusTransform.cpp:9-67  CensusTransform (generic N x N).
+ * maskSize = size made odd (:10-13); nWords = maskSize^2/32 + 1 (:17); a pixel
+ * within maskSize/2 of any border gets all-zero words (:36-37).  Bit j*m+i
+ * (+pass) is set when neighbour >= centre (:56) -- the opposite polarity of
+ * a2, and the centre itself is compared, so its bit is set.  The skip test
+ * (:47) compares the WINDOW index (i,j) with the IMAGE coordinate (u,v): it
+ * fires only for pixels with u,v < m, skips that (non-centre) tap and shifts
+ * every later bit down by one (pass = -1).  Restated exactly.
+ * out holds nWords words per pixel, pixel-major.  The reference's callers hand
+ * an unsigned image to the signed parameter (denseCensusStereo.cpp:307-308),
+ * which OpenCV converts with saturation: orc_u8_saturate_s8 restates that. */
+ORC_API int orc_census_nxn_words(int size) { const int m = (size % 2 == 0) ? size + 1 : size; return (m * m) / 32 + 1; }
+ORC_API void orc_u8_saturate_s8(const uint8_t *src, int8_t *dst, size_t n) {
+    for (size_t i = 0; i < n; ++i) dst[i] = (int8_t)(src[i] > 127 ? 127 : src[i]);
+}
+ORC_API void orc_census_nxn(const int8_t *in, int rows, int cols, int size, uint32_t *out) {
+    const int m = (size % 2 == 0) ? size + 1 : size, h = m / 2;
+    const int nw = (m * m) / 32 + 1;
+    for (int v = 0; v < rows; ++v)
+        for (int u = 0; u < cols; ++u) {
+            uint32_t *w = out + ((long)v * cols + u) * nw;
+            for (int k = 0; k < nw; ++k) w[k] = 0;
+            if (u < h || v < h || u >= cols - h || v >= rows - h) continue;
+            const int8_t ref = in[(long)v * cols + u];
+            int pass = 0;
+            for (int j = 0; j < m; ++j)
+                for (int i = 0; i < m; ++i) {
+                    if (j == v && i == u) { pass = -1; continue; }
+                    if (in[(long)(v - h + j) * cols + (u - h + i)] >= ref) {
+                        const int bit = j * m + i + pass;
+                        w[bit / 32] |= 1u << (bit % 32);
+                    }
+                }
+        }
+}

@@ -35,6 +35,10 @@ EXPORTS = {
     "svx_dense_wta5x5": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svx_dense_census_wta_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svx_epipolar_match_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "svx_census_nxn_words": (_i, [_i]),
+    "svx_census_nxn_s8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "svx_census_nxn_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "svx_support_resampling": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [_vp] * 7 + [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "svx_cost_eval": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "svx_refine": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, C.c_uint, _vp, _vp] + [_vp] * 7),
     "svx_plane_fit": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
@@ -162,6 +166,37 @@ class Context:
         else:
             self._call("svx_census5x5_s8", _dptr(_check_dev(img, t.int8, "img")), _dptr(out), r, c, f, flags)
         return out
+
+    # ---- a14 ----
+    def census_nxn(self, img, size):
+        t = self._torch
+        f, r, c = _frames(img)
+        nw = self._lib.svx_census_nxn_words(int(size))
+        out = t.empty(tuple(img.shape) + (nw,), dtype=t.int32, device=img.device)
+        if img.dtype == t.uint8:
+            self._call("svx_census_nxn_u8", _dptr(_check_dev(img, t.uint8, "img")), r, c, f, int(size), _dptr(out))
+        else:
+            self._call("svx_census_nxn_s8", _dptr(_check_dev(img, t.int8, "img")), r, c, f, int(size), _dptr(out))
+        return out
+
+    # ---- a13 ----
+    def support_resampling(self, census_left, census_right, grid, census_size, aggr, t_low, t_high, max_disp, disparities):
+        """grid: the dict returned by refine().  Returns (xy [n,2] int32, d [n] float32) of the new support points
+        in the reference's insertion order (host arrays); `disparities` is updated in place on the device."""
+        t = self._torch
+        _check_dev(census_left, t.int32, "census_left"); _check_dev(census_right, t.int32, "census_right")
+        _check_dev(disparities, t.float32, "disparities")
+        nc = grid["gw"] * grid["gh"]
+        dev = disparities.device
+        oxy = t.empty((2 * nc, 2), dtype=t.int32, device=dev)
+        od = t.empty(2 * nc, dtype=t.float32, device=dev)
+        ov = t.empty(2 * nc, dtype=t.uint8, device=dev)
+        self._call("svx_support_resampling", _dptr(census_left), _dptr(census_right), census_left.shape[0], census_left.shape[1],
+                   int(census_size), int(aggr), grid["gw"], grid["gh"], _dptr(grid["conf_x"]), _dptr(grid["conf_y"]),
+                   _dptr(grid["conf_d"]), _dptr(grid["conf_c"]), _dptr(grid["inv_x"]), _dptr(grid["inv_y"]), _dptr(grid["inv_c"]),
+                   int(t_low), int(t_high), int(max_disp), _dptr(disparities), _dptr(oxy), _dptr(od), _dptr(ov))
+        keep = ov.bool().cpu().numpy()
+        return oxy.cpu().numpy()[keep], od.cpu().numpy()[keep]
 
     # ---- a4 ----
     def census_window_cost(self, ref, cmp_, ref_xy, cmp_xy, mode=WINDOW_5X6):

@@ -235,3 +235,63 @@ SVX_API int svx_census5x5_s8(svx_ctx *ctx, const int8_t *in, uint32_t *out, int 
 SVX_API int svx_census5x5_u8(svx_ctx *ctx, const uint8_t *in, uint32_t *out, int rows, int cols, int n_frames, int flags) {
     return census_dispatch<true>(ctx, in, out, rows, cols, n_frames, flags, "census5x5 (u8)");
 }
+
+// ---------------------------------------------------------------- a14 ----
+// Generic N x N census of denseCensusStereo/CensusTransform.cpp:33-67: bit j*m+i set when neighbour >=
+// centre, the window-index-versus-image-coordinate skip test included.  One thread per pixel; this
+// variant is not on the fast path of the reference either.
+template <bool FROM_U8>
+__global__ __launch_bounds__(256) void census_nxn_kernel(const uint8_t *__restrict__ in_all, int rows, int cols, int m, int nw,
+                                                         uint32_t *__restrict__ out_all) {
+    const long n = (long)rows * cols;
+    const uint8_t *in = in_all + (long)blockIdx.z * n;
+    uint32_t *out = out_all + (long)blockIdx.z * n * nw;
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= cols || v >= rows) return;
+    auto px = [&](long o) -> int { return FROM_U8 ? min((int)in[o], 127) : (int)(int8_t)in[o]; };   // u8 -> s8 saturates
+    uint32_t *w = out + ((long)v * cols + u) * nw;
+    const int h = m / 2;
+    if (u < h || v < h || u >= cols - h || v >= rows - h) {
+        for (int k = 0; k < nw; ++k) w[k] = 0u;
+        return;
+    }
+    const int ref = px((long)v * cols + u);
+    uint32_t acc = 0;
+    int word = 0, pass = 0;
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) {
+            if (j == v && i == u) { pass = -1; continue; }
+            const int bit = j * m + i + pass;
+            if ((bit >> 5) != word) { w[word] = acc; acc = 0u; ++word; }
+            if (px((long)(v - h + j) * cols + (u - h + i)) >= ref) acc |= 1u << (bit & 31);
+        }
+    w[word] = acc;
+    for (int k = word + 1; k < nw; ++k) w[k] = 0u;
+}
+
+template <bool FROM_U8>
+static int census_nxn_dispatch(svx_ctx *ctx, const void *in, int rows, int cols, int n_frames, int size, uint32_t *out) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, in && out, SVX_ERR_INVALID_ARG, "svx_census_nxn: null image pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "svx_census_nxn: empty image");
+    SVX_REQUIRE(ctx, size >= 1 && size <= 31, SVX_ERR_UNSUPPORTED, "svx_census_nxn: size must be in [1, 31]");
+    SVX_REQUIRE(ctx, n_frames <= 65535, SVX_ERR_UNSUPPORTED, "svx_census_nxn: more than 65535 frames per call");
+    const int m = (size % 2 == 0) ? size + 1 : size;
+    dim3 grid(svx_cdiv(cols, 64), svx_cdiv(rows, 4), n_frames);
+    census_nxn_kernel<FROM_U8><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)in, rows, cols, m, (m * m) / 32 + 1, out);
+    SVX_LAUNCH_CHECK(ctx, "census_nxn_kernel");
+    return SVX_OK;
+}
+
+SVX_API int svx_census_nxn_words(int size) {
+    if (size < 1) return 0;
+    const int m = (size % 2 == 0) ? size + 1 : size;
+    return (m * m) / 32 + 1;
+}
+SVX_API int svx_census_nxn_s8(svx_ctx *ctx, const int8_t *in, int rows, int cols, int n_frames, int size, uint32_t *out) {
+    return census_nxn_dispatch<false>(ctx, in, rows, cols, n_frames, size, out);
+}
+SVX_API int svx_census_nxn_u8(svx_ctx *ctx, const uint8_t *in, int rows, int cols, int n_frames, int size, uint32_t *out) {
+    return census_nxn_dispatch<true>(ctx, in, rows, cols, n_frames, size, out);
+}

@@ -9,14 +9,10 @@
 // and evaluate the whole A x A aggregate; the winner is the minimum of
 // (cost << 32 | d), i.e. the smallest disparity among equal costs, which is
 // what a strict '<' scan from d = 0 upwards keeps.
-__global__ __launch_bounds__(256) void epipolar_match_kernel(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
-                                                             int half, int margin, const int32_t *__restrict__ pts_xy, int n_pts, int max_disp,
-                                                             float *__restrict__ out_disp, int8_t *__restrict__ out_cost) {
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (p >= n_pts) return;
+// Full-range search for one point by one wavefront; every lane returns the winning disparity.
+__device__ __forceinline__ int epipolar_search(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                               int half, int margin, int x, int y, int max_disp, int lane) {
     const long n = (long)rows * cols;
-    const int x = pts_xy[2 * p], y = pts_xy[2 * p + 1];
     unsigned long long best = ~0ull;
     for (int d = lane; d < max_disp; d += 64) {
         const int i = x - d;
@@ -36,10 +32,57 @@ __global__ __launch_bounds__(256) void epipolar_match_kernel(const uint32_t *__r
         const unsigned long long o = __shfl_xor(best, s, 64);
         best = o < best ? o : best;
     }
+    return best == ~0ull ? 0 : (int)(unsigned)(best & 0xffffffffu);
+}
+
+__device__ __forceinline__ int single_pixel_cost(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                                 int x, int y, int d) {
+    const long n = (long)rows * cols;
+    return popc32(ld_guard_u32(cl, n, (long)y * cols + x) ^ ld_guard_u32(cr, n, (long)y * cols + (x - d)));
+}
+
+__global__ __launch_bounds__(256) void epipolar_match_kernel(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                                             int half, int margin, const int32_t *__restrict__ pts_xy, int n_pts, int max_disp,
+                                                             float *__restrict__ out_disp, int8_t *__restrict__ out_cost) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= n_pts) return;
+    const int x = pts_xy[2 * p], y = pts_xy[2 * p + 1];
+    const int d = epipolar_search(cl, cr, rows, cols, half, margin, x, y, max_disp, lane);
     if (lane == 0) {
-        const int d = best == ~0ull ? 0 : (int)(unsigned)(best & 0xffffffffu);
         out_disp[p] = (float)d;
-        out_cost[p] = (int8_t)popc32(ld_guard_u32(cl, n, (long)y * cols + x) ^ ld_guard_u32(cr, n, (long)y * cols + (x - d)));
+        out_cost[p] = (int8_t)single_pixel_cost(cl, cr, rows, cols, x, y, d);
+    }
+}
+
+// a13: one wavefront per occupancy-grid cell.  Slot 2c holds the re-matched invalid point of cell c,
+// slot 2c+1 its confident support; out_valid marks the slots that became support points.
+__global__ __launch_bounds__(256) void support_resampling_kernel(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                                                 int half, int margin, int n_cells,
+                                                                 const int32_t *__restrict__ conf_x, const int32_t *__restrict__ conf_y,
+                                                                 const float *__restrict__ conf_d, const int8_t *__restrict__ conf_c,
+                                                                 const int32_t *__restrict__ inv_x, const int32_t *__restrict__ inv_y,
+                                                                 const int8_t *__restrict__ inv_c, int t_low, int t_high, int max_disp,
+                                                                 float *__restrict__ disparities, int32_t *__restrict__ out_xy,
+                                                                 float *__restrict__ out_d, uint8_t *__restrict__ out_valid) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= n_cells) return;
+    bool inv_ok = false;
+    int ix = inv_x[c], iy = inv_y[c], d = 0;
+    if ((int)inv_c[c] > t_high) {          // wavefront-uniform
+        d = epipolar_search(cl, cr, rows, cols, half, margin, ix, iy, max_disp, lane);
+        inv_ok = (int)(int8_t)single_pixel_cost(cl, cr, rows, cols, ix, iy, d) < t_low;
+    }
+    if (lane == 0) {
+        out_valid[2 * c] = inv_ok ? 1 : 0;
+        out_xy[4 * c] = ix; out_xy[4 * c + 1] = iy; out_d[2 * c] = (float)d;
+        if (inv_ok && ix >= 0 && ix < cols && iy >= 0 && iy < rows) disparities[(long)iy * cols + ix] = (float)d;
+        const bool conf_ok = (int)conf_c[c] < t_low;
+        const int cx = conf_x[c], cy = conf_y[c];
+        out_valid[2 * c + 1] = conf_ok ? 1 : 0;
+        out_xy[4 * c + 2] = cx; out_xy[4 * c + 3] = cy; out_d[2 * c + 1] = conf_d[c];
+        if (conf_ok && cx >= 0 && cx < cols && cy >= 0 && cy < rows) disparities[(long)cy * cols + cx] = conf_d[c];
     }
 }
 
@@ -57,6 +100,28 @@ SVX_API int svx_epipolar_match_batch(svx_ctx *ctx, const uint32_t *census_left, 
     epipolar_match_kernel<<<svx_cdiv(n_pts, 4), 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, cost_aggr_window_size / 2,
                                                                       census_size / 2, pts_xy, n_pts, max_disp, out_disp, out_cost);
     SVX_LAUNCH_CHECK(ctx, "epipolar_match_kernel");
+    return SVX_OK;
+}
+
+SVX_API int svx_support_resampling(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                                   int census_size, int cost_aggr_window_size, int grid_w, int grid_h,
+                                   const int32_t *conf_x, const int32_t *conf_y, const float *conf_d, const int8_t *conf_c,
+                                   const int32_t *inv_x, const int32_t *inv_y, const int8_t *inv_c,
+                                   int t_low, int t_high, int max_disp, float *disparities,
+                                   int32_t *out_xy, float *out_d, uint8_t *out_valid) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, census_left && census_right && disparities, SVX_ERR_INVALID_ARG, "svx_support_resampling: null image pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_support_resampling: empty image");
+    SVX_REQUIRE(ctx, grid_w > 0 && grid_h > 0 && (long)grid_w * grid_h <= 0x3fffffff, SVX_ERR_INVALID_ARG, "svx_support_resampling: bad grid size");
+    SVX_REQUIRE(ctx, conf_x && conf_y && conf_d && conf_c && inv_x && inv_y && inv_c && out_xy && out_d && out_valid,
+                SVX_ERR_INVALID_ARG, "svx_support_resampling: null grid or output pointer");
+    SVX_REQUIRE(ctx, census_size >= 1 && cost_aggr_window_size >= 1, SVX_ERR_INVALID_ARG, "svx_support_resampling: window sizes must be >= 1");
+    const int n_cells = grid_w * grid_h;
+    support_resampling_kernel<<<svx_cdiv(n_cells, 4), 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, cost_aggr_window_size / 2,
+                                                                            census_size / 2, n_cells, conf_x, conf_y, conf_d, conf_c, inv_x, inv_y,
+                                                                            inv_c, t_low, t_high, max_disp, disparities, out_xy, out_d, out_valid);
+    SVX_LAUNCH_CHECK(ctx, "support_resampling_kernel");
     return SVX_OK;
 }
 

@@ -40,6 +40,12 @@ lib.orc_sparse_match.restype = C.c_int
 lib.orc_sparse_match.argtypes = [_p, _p, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int,
                                  C.c_int, C.c_float, C.c_float, C.c_int, _p, _p, _p]
 lib.orc_plane_fit.argtypes = [_p, _p]
+lib.orc_support_resampling.restype = C.c_int
+lib.orc_support_resampling.argtypes = [_p, _p] + [C.c_int] * 6 + [_p] * 7 + [C.c_int] * 3 + [_p, _p, _p]
+lib.orc_census_nxn_words.restype = C.c_int
+lib.orc_census_nxn_words.argtypes = [C.c_int]
+lib.orc_u8_saturate_s8.argtypes = [_p, _p, C.c_size_t]
+lib.orc_census_nxn.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p]
 lib.orc_plane_prior_raster.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p]
 
 
@@ -126,6 +132,34 @@ def sparse_match(cl, cr, left_xy, right_xy, max_disp, y_tol=1.0, uniqueness=0.6,
     n = lib.orc_sparse_match(_ptr(cl), _ptr(cr), rows, cols, _ptr(left_xy), nl, _ptr(right_xy), nr,
                              max_disp, y_tol, uniqueness, lr_step, _ptr(ol), _ptr(orr), _ptr(oc))
     return ol[:n], orr[:n], oc[:n]
+
+
+def support_resampling(cl, cr, g, census_size, aggr, t_low, t_high, max_disp, disparities):
+    rows, cols = cl.shape
+    nc = g["gw"] * g["gh"]
+    oxy = np.zeros((2 * nc, 2), np.int32)
+    od = np.zeros(2 * nc, np.float32)
+    n = lib.orc_support_resampling(_ptr(cl), _ptr(cr), rows, cols, census_size, aggr, g["gw"], g["gh"],
+                                   _ptr(g["conf_x"]), _ptr(g["conf_y"]), _ptr(g["conf_d"]), _ptr(g["conf_c"]),
+                                   _ptr(g["inv_x"]), _ptr(g["inv_y"]), _ptr(g["inv_c"]), t_low, t_high, max_disp,
+                                   _ptr(disparities), _ptr(oxy), _ptr(od))
+    return oxy[:n], od[:n]
+
+
+def u8_saturate_s8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty(img.shape, np.int8)
+    lib.orc_u8_saturate_s8(_ptr(img), _ptr(out), img.size)
+    return out
+
+
+def census_nxn(img_s8, size):
+    img_s8 = np.ascontiguousarray(img_s8, dtype=np.int8)
+    rows, cols = img_s8.shape
+    nw = lib.orc_census_nxn_words(size)
+    out = np.empty((rows, cols, nw), np.uint32)
+    lib.orc_census_nxn(_ptr(img_s8), rows, cols, size, _ptr(out))
+    return out
 
 
 def plane_fit(xyd):

@@ -359,3 +359,57 @@ def test_cpp_reference_api_program():
     p = subprocess.run([exe], capture_output=True, text=True, timeout=100)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "reference-api checks passed" in p.stdout
+
+
+# ------------------------------------------------------------------ full benchmark sizes of the other configs
+@pytest.mark.parametrize("rows,cols,D,check_rows", [(1072, 1920, 256, (500, 503)), (2160, 3840, 512, (1000, 1002))])
+def test_dense_wta_full_size_configs(ctx, rows, cols, D, check_rows):
+    """configs[3] (1920x1080 cropped to /16, D=256) and configs[4] (3840x2160, D=512): border, range and a
+    few complete rows against the oracle (rows are independent given the census images)."""
+    from stereovision_amd import synth
+    left, right, field = synth.stereo_pair(rows, cols, D, seed=7)
+    d = ctx.dense_census_wta(dev(left), dev(right), D).cpu().numpy()
+    assert d[:2].max() == 0 and d[-2:].max() == 0 and d[:, :2].max() == 0 and d[:, -2:].max() == 0
+    assert d.max() <= D - 1 and d.min() >= 0
+    inner = (slice(8, rows - 8), slice(D + 8, cols - 8))
+    assert float(np.mean(d[inner] == field[inner])) > 0.97
+    cl = O.census5x5(O.u8_to_s8(left)); cr = O.census5x5(O.u8_to_s8(right))
+    want = np.zeros((rows, cols), np.float32)
+    y0, y1 = check_rows
+    O.lib.orc_dense_wta5x5_rows(cl.ctypes.data, cr.ctypes.data, rows, cols, D, want.ctypes.data, y0, y1)
+    assert np.array_equal(d[y0:y1], want[y0:y1])
+    # strip seams of the sweep kernel (strips of 96 output rows from row 2)
+    O.lib.orc_dense_wta5x5_rows(cl.ctypes.data, cr.ctypes.data, rows, cols, D, want.ctypes.data, 96, 100)
+    assert np.array_equal(d[96:100], want[96:100])
+
+
+# ------------------------------------------------------------------ a13 / a14
+def test_support_resampling(ctx):
+    rows, cols, grid = 64, 160, 16
+    cl, cr, prior, pts = _prior_case(rows, cols, 77, 0.5)
+    t_low, t_high, D = 2, 10, 40
+    costs = np.full((rows, cols), t_high, np.int8); O.cost_eval(cl, cr, pts, prior, costs)
+    fd = np.zeros((rows, cols), np.float32); fc = np.full((rows, cols), 25, np.int8)
+    g_w = O.refine(pts, prior, costs, t_low, t_high, grid, fd, fc)
+    prior_w = prior.copy()
+    wxy, wd = O.support_resampling(cl, cr, g_w, 5, 11, t_low, t_high, D, prior_w)
+    g_g = ctx.refine(dev(pts), dev(prior), dev(costs), t_low, t_high, grid, dev(np.zeros((rows, cols), np.float32)),
+                     dev(np.full((rows, cols), 25, np.int8)))
+    prior_g = dev(prior.copy())
+    gxy, gd = ctx.support_resampling(dev_u32(cl), dev_u32(cr), g_g, 5, 11, t_low, t_high, D, prior_g)
+    assert len(wxy) > 10
+    assert np.array_equal(gxy, wxy) and np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+    assert np.array_equal(prior_g.cpu().numpy().view(np.uint32), prior_w.view(np.uint32))
+
+
+@pytest.mark.parametrize("size", [5, 4, 7, 9, 3, 1])
+def test_census_nxn(ctx, size):
+    rng = np.random.default_rng(size)
+    img = rng.integers(0, 256, size=(23, 37), dtype=np.uint8)
+    want = O.census_nxn(O.u8_saturate_s8(img), size)
+    got_u8 = u32(ctx.census_nxn(dev(img), size))
+    assert got_u8.shape == want.shape and np.array_equal(got_u8, want)
+    s8 = rng.integers(-128, 128, size=(2, 19, 24), dtype=np.int8)
+    got = u32(ctx.census_nxn(dev(s8), size))
+    for f in range(2):
+        assert np.array_equal(got[f], O.census_nxn(s8[f], size))
