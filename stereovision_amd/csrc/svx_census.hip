@@ -55,52 +55,228 @@ constexpr int CT_W = 256;            // tile width in pixels (one wave spans it:
 constexpr int CT_H = 16;             // tile height: 4 waves x 4 rows
 constexpr int CT_LROW = CT_W / 4 + 2;  // dwords per staged row: columns x0-4 .. x0+CT_W+3
 
-// One comparison bit: word = 2*word + (centre > neighbour), both operands picked as unsigned bytes straight
-// out of packed registers by SDWA (no extraction instructions).  Pixels are kept in the UNSIGNED domain
-// (signed input is biased by 0x80 at staging), where the reference's signed compare is an unsigned one.
-#define CENSUS_BIT(WORD, CREG, CB, NREG, NB)                                                                   \
-    asm("v_cmp_gt_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #CB " src1_sel:BYTE_" #NB "\n\t"                         \
-        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc"                                                               \
-        : "+v"(WORD) : "v"(CREG), "v"(NREG) : "vcc")
+// The 24 bits of one pixel, most significant first (idx = 0..24 without the centre): word = 2*word +
+// (centre > neighbour) per step, both operands picked as unsigned bytes straight out of packed registers by
+// SDWA (no extraction instructions), the compare result carried into the word by an add-with-carry.  Pixels
+// are kept in the UNSIGNED domain (signed input is biased by 0x80 at staging), where the reference's signed
+// compare is an unsigned one.  Row windows: L[r] = columns x-2..x+1, H[r] = columns x+2..x+5 of row r of the
+// 5-row window; neighbour (dy,dx) of pixel I is window byte 2+I+dx of row dy+2, the centre byte 2+I of row 2.
+// One asm block per pixel (48 instructions).
+#define CENSUS_PX0(WORD, L, H)                                                             \
+    asm(                                                                                       \
+        "v_cmp_gt_u32_sdwa vcc, %3, %1 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %1 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %1 src0_sel:BYTE_2 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %1 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %6 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:BYTE_2 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %7 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %3 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %3 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %3 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %8 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %4 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %4 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %4 src0_sel:BYTE_2 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %4 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %9 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:BYTE_2 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %10 src0_sel:BYTE_2 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        : "+v"(WORD)                                                                       \
+        : "v"(L[0]), "v"(L[1]), "v"(L[2]), "v"(L[3]), "v"(L[4]), "v"(H[0]), "v"(H[1]), "v"(H[2]), "v"(H[3]), "v"(H[4]) \
+        : "vcc")
 
-// The 24 bits of pixel I (0..3) of a 4-pixel group, most significant first (idx = 0..24 without the centre).
-// Row windows: lo = columns x-2..x+1, hi = columns x+2..x+5; neighbour (dy,dx) of pixel I is window byte
-// 2+I+dx of row dy+2, the centre is window byte 2+I of row 2.
-#define CENSUS_ROW5(WORD, CREG, CB, LO, HI, B0, R0, B1, R1, B2, R2, B3, R3, B4, R4)                             \
-    CENSUS_BIT(WORD, CREG, CB, R0, B0); CENSUS_BIT(WORD, CREG, CB, R1, B1); CENSUS_BIT(WORD, CREG, CB, R2, B2); \
-    CENSUS_BIT(WORD, CREG, CB, R3, B3); CENSUS_BIT(WORD, CREG, CB, R4, B4)
-#define CENSUS_ROW4(WORD, CREG, CB, B0, R0, B1, R1, B3, R3, B4, R4)                                             \
-    CENSUS_BIT(WORD, CREG, CB, R0, B0); CENSUS_BIT(WORD, CREG, CB, R1, B1);                                     \
-    CENSUS_BIT(WORD, CREG, CB, R3, B3); CENSUS_BIT(WORD, CREG, CB, R4, B4)
+#define CENSUS_PX1(WORD, L, H)                                                             \
+    asm(                                                                                       \
+        "v_cmp_gt_u32_sdwa vcc, %3, %1 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %1 src0_sel:BYTE_3 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %1 src0_sel:BYTE_3 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %6 src0_sel:BYTE_3 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %6 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:BYTE_3 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:BYTE_3 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %7 src0_sel:BYTE_3 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %7 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %3 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %3 src0_sel:BYTE_3 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %8 src0_sel:BYTE_3 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %8 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %4 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %4 src0_sel:BYTE_3 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %4 src0_sel:BYTE_3 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %9 src0_sel:BYTE_3 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %9 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:BYTE_3 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:BYTE_3 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %10 src0_sel:BYTE_3 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %3, %10 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        : "+v"(WORD)                                                                       \
+        : "v"(L[0]), "v"(L[1]), "v"(L[2]), "v"(L[3]), "v"(L[4]), "v"(H[0]), "v"(H[1]), "v"(H[2]), "v"(H[3]), "v"(H[4]) \
+        : "vcc")
 
-// pixel 0: window bytes 0..4 = lo.0 lo.1 lo.2 lo.3 hi.0, centre lo.2
-#define CENSUS_PX0(WORD, L, H)                                                                                 \
-    CENSUS_ROW5(WORD, L[2], 2, , , 0, L[0], 1, L[0], 2, L[0], 3, L[0], 0, H[0]);                                \
-    CENSUS_ROW5(WORD, L[2], 2, , , 0, L[1], 1, L[1], 2, L[1], 3, L[1], 0, H[1]);                                \
-    CENSUS_ROW4(WORD, L[2], 2, 0, L[2], 1, L[2], 3, L[2], 0, H[2]);                                             \
-    CENSUS_ROW5(WORD, L[2], 2, , , 0, L[3], 1, L[3], 2, L[3], 3, L[3], 0, H[3]);                                \
-    CENSUS_ROW5(WORD, L[2], 2, , , 0, L[4], 1, L[4], 2, L[4], 3, L[4], 0, H[4])
-// pixel 1: window bytes 1..5 = lo.1 lo.2 lo.3 hi.0 hi.1, centre lo.3
-#define CENSUS_PX1(WORD, L, H)                                                                                 \
-    CENSUS_ROW5(WORD, L[2], 3, , , 1, L[0], 2, L[0], 3, L[0], 0, H[0], 1, H[0]);                                \
-    CENSUS_ROW5(WORD, L[2], 3, , , 1, L[1], 2, L[1], 3, L[1], 0, H[1], 1, H[1]);                                \
-    CENSUS_ROW4(WORD, L[2], 3, 1, L[2], 2, L[2], 0, H[2], 1, H[2]);                                             \
-    CENSUS_ROW5(WORD, L[2], 3, , , 1, L[3], 2, L[3], 3, L[3], 0, H[3], 1, H[3]);                                \
-    CENSUS_ROW5(WORD, L[2], 3, , , 1, L[4], 2, L[4], 3, L[4], 0, H[4], 1, H[4])
-// pixel 2: window bytes 2..6 = lo.2 lo.3 hi.0 hi.1 hi.2, centre hi.0
-#define CENSUS_PX2(WORD, L, H)                                                                                 \
-    CENSUS_ROW5(WORD, H[2], 0, , , 2, L[0], 3, L[0], 0, H[0], 1, H[0], 2, H[0]);                                \
-    CENSUS_ROW5(WORD, H[2], 0, , , 2, L[1], 3, L[1], 0, H[1], 1, H[1], 2, H[1]);                                \
-    CENSUS_ROW4(WORD, H[2], 0, 2, L[2], 3, L[2], 1, H[2], 2, H[2]);                                             \
-    CENSUS_ROW5(WORD, H[2], 0, , , 2, L[3], 3, L[3], 0, H[3], 1, H[3], 2, H[3]);                                \
-    CENSUS_ROW5(WORD, H[2], 0, , , 2, L[4], 3, L[4], 0, H[4], 1, H[4], 2, H[4])
-// pixel 3: window bytes 3..7 = lo.3 hi.0 hi.1 hi.2 hi.3, centre hi.1
-#define CENSUS_PX3(WORD, L, H)                                                                                 \
-    CENSUS_ROW5(WORD, H[2], 1, , , 3, L[0], 0, H[0], 1, H[0], 2, H[0], 3, H[0]);                                \
-    CENSUS_ROW5(WORD, H[2], 1, , , 3, L[1], 0, H[1], 1, H[1], 2, H[1], 3, H[1]);                                \
-    CENSUS_ROW4(WORD, H[2], 1, 3, L[2], 0, H[2], 2, H[2], 3, H[2]);                                             \
-    CENSUS_ROW5(WORD, H[2], 1, , , 3, L[3], 0, H[3], 1, H[3], 2, H[3], 3, H[3]);                                \
-    CENSUS_ROW5(WORD, H[2], 1, , , 3, L[4], 0, H[4], 1, H[4], 2, H[4], 3, H[4])
+#define CENSUS_PX2(WORD, L, H)                                                             \
+    asm(                                                                                       \
+        "v_cmp_gt_u32_sdwa vcc, %8, %1 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %1 src0_sel:BYTE_0 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %6 src0_sel:BYTE_0 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %6 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %6 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %2 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %2 src0_sel:BYTE_0 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %7 src0_sel:BYTE_0 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %7 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %7 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %3 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %3 src0_sel:BYTE_0 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %8 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %8 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %4 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %4 src0_sel:BYTE_0 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %9 src0_sel:BYTE_0 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %9 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %9 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %5 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %5 src0_sel:BYTE_0 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %10 src0_sel:BYTE_0 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %10 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %10 src0_sel:BYTE_0 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        : "+v"(WORD)                                                                       \
+        : "v"(L[0]), "v"(L[1]), "v"(L[2]), "v"(L[3]), "v"(L[4]), "v"(H[0]), "v"(H[1]), "v"(H[2]), "v"(H[3]), "v"(H[4]) \
+        : "vcc")
+
+#define CENSUS_PX3(WORD, L, H)                                                             \
+    asm(                                                                                       \
+        "v_cmp_gt_u32_sdwa vcc, %8, %1 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %6 src0_sel:BYTE_1 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %6 src0_sel:BYTE_1 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %6 src0_sel:BYTE_1 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %6 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %2 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %7 src0_sel:BYTE_1 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %7 src0_sel:BYTE_1 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %7 src0_sel:BYTE_1 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %7 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %3 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %8 src0_sel:BYTE_1 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %8 src0_sel:BYTE_1 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %8 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %4 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %9 src0_sel:BYTE_1 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %9 src0_sel:BYTE_1 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %9 src0_sel:BYTE_1 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %9 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %5 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %10 src0_sel:BYTE_1 src1_sel:BYTE_0\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %10 src0_sel:BYTE_1 src1_sel:BYTE_1\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %10 src0_sel:BYTE_1 src1_sel:BYTE_2\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        "v_cmp_gt_u32_sdwa vcc, %8, %10 src0_sel:BYTE_1 src1_sel:BYTE_3\n\t" \
+        "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t" \
+        : "+v"(WORD)                                                                       \
+        : "v"(L[0]), "v"(L[1]), "v"(L[2]), "v"(L[3]), "v"(L[4]), "v"(H[0]), "v"(H[1]), "v"(H[2]), "v"(H[3]), "v"(H[4]) \
+        : "vcc")
 
 // Requires cols % 4 == 0 and 4-byte aligned frame bases, so that every staged
 // dword lies entirely inside or entirely outside the frame.

@@ -161,17 +161,8 @@ SVX_API int svx_cost_eval(svx_ctx *ctx, const uint32_t *census_left, const uint3
 // Per-point accept step plus per-cell winners.  A sequential scan with strict
 // compares keeps, per cell, the lowest cost below tLow (confident support) and
 // the highest cost above tHigh (invalid match), earliest point first; that is
-// the minimum of the keys below, found with one 64-bit atomic per wavefront
-// when the wavefront's points share a cell and one per lane otherwise.
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const unsigned long long o = __shfl_xor(v, s, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
+// the minimum of the keys below, found with a segmented wavefront scan over
+// runs of equal cells and one 64-bit atomic per run.
 __global__ __launch_bounds__(256) void refine_points_kernel(const int32_t *__restrict__ pts_xy, int n_pts, const float *__restrict__ disp,
                                                             const int8_t *__restrict__ costs, int rows, int cols, int t_low, int t_high,
                                                             int grid_size, int grid_w, float *__restrict__ final_disp, int8_t *__restrict__ final_costs,
@@ -192,18 +183,22 @@ __global__ __launch_bounds__(256) void refine_points_kernel(const int32_t *__res
             if (mc > t_high) ik = ((unsigned long long)(unsigned)(127 - mc) << 32) | (unsigned)p;
         }
     }
-    const int first = __builtin_amdgcn_readfirstlane(cell);
-    if (__all(cell == first || cell < 0)) {
-        // every valid lane of this wavefront is in one cell (or the first lane is invalid and all are)
-        const unsigned long long c = wave_min_u64(ck), i = wave_min_u64(ik);
-        int tgt = cell;
+    // Points come in raster order, so the lanes of one cell form contiguous runs.  A segmented min-scan
+    // (lane l takes lane l-s while it is in the same cell) leaves each run's minimum in the run's last
+    // lane, which issues the only atomics of that run.
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) tgt = max(tgt, __shfl_xor(tgt, s, 64));
-        if ((threadIdx.x & 63) == 0 && tgt >= 0) {
-            if (c != ~0ull) atomicMin(conf_key + tgt, c);
-            if (i != ~0ull) atomicMin(inv_key + tgt, i);
+    for (int s = 1; s < 64; s <<= 1) {
+        const int oc = __shfl_up(cell, s, 64);
+        const unsigned long long c2 = __shfl_up(ck, s, 64), i2 = __shfl_up(ik, s, 64);
+        if (lane >= s && oc == cell) {
+            ck = c2 < ck ? c2 : ck;
+            ik = i2 < ik ? i2 : ik;
         }
-    } else if (cell >= 0) {
+    }
+    const int next = __shfl_down(cell, 1, 64);
+    const bool tail = lane == 63 || next != cell;
+    if (tail && cell >= 0) {
         if (ck != ~0ull) atomicMin(conf_key + cell, ck);
         if (ik != ~0ull) atomicMin(inv_key + cell, ik);
     }
