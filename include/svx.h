@@ -191,6 +191,48 @@ int svx_plane_fit(svx_ctx *ctx, const int32_t *tri_xy, int n_tri, const float *d
 int svx_plane_prior_raster(svx_ctx *ctx, const int32_t *tri_xy, const float *tri_abc, int n_tri,
                            int rows, int cols, float *prior);
 
+/* ---- steps either side of the census path ----------------------------------
+ * Pre-processing of highPerfStereo(), highPerfStereoLib.cpp:245-335.  Its
+ * arithmetic is OpenCV's (not part of the reference tree); the entry points
+ * restate OpenCV's documented behaviour for 8-bit single-channel images.
+ *
+ * svx_crop16: newROI(0,0,16*(cols/16),16*(rows/16)), .cpp:245-247; dst is
+ *   densely packed [n_frames][16*(rows/16)][16*(cols/16)].
+ * svx_equalize_hist: cv::equalizeHist, .cpp:251-252 (src == dst allowed).
+ * svx_laplacian_abs: cv::Laplacian(ddepth CV_16S, ksize 1|3, scale, delta,
+ *   BORDER_DEFAULT) followed by cv::convertScaleAbs, .cpp:258-259.
+ * svx_high_gradient_points: the point set of .cpp:269-280 (2 <= y < rows-2,
+ *   2 <= x < cols-2, pixel > threshold) in the reference's push order, frames
+ *   concatenated; frame_offsets_host[f]..[f+1] (n_frames+1 host ints) delimit
+ *   frame f.  Points past `capacity` are counted but not stored.  Synchronous.
+ * svx_gaussian_blur: cv::GaussianBlur(Size(k,k), 0, 0), .cpp:289-292, k in
+ *   {1,3,5}; the reference passes k = (int)applyBlur = 1 (.cpp:207), a copy.
+ * svx_alter_rows: the row-band inversion and line tracing applied to the
+ *   detector's input copies, .cpp:300-335, in place. */
+int svx_crop16(svx_ctx *ctx, const uint8_t *src, int rows, int cols, int n_frames, uint8_t *dst);
+int svx_equalize_hist(svx_ctx *ctx, const uint8_t *src, uint8_t *dst, int rows, int cols, int n_frames);
+int svx_laplacian_abs(svx_ctx *ctx, const uint8_t *src, uint8_t *abs_grad, int rows, int cols, int n_frames,
+                      int ksize, double scale, double delta);
+int svx_high_gradient_points(svx_ctx *ctx, const uint8_t *abs_grad, int rows, int cols, int n_frames, int threshold,
+                             int32_t *pts_xy, int capacity, int *frame_offsets_host);
+int svx_gaussian_blur(svx_ctx *ctx, const uint8_t *src, uint8_t *dst, int rows, int cols, int n_frames, int ksize);
+int svx_alter_rows(svx_ctx *ctx, uint8_t *img, int rows, int cols, int n_frames, int invert_rows, int nb_rows,
+                   int trace_lines, int nb_lines, int line_size);
+
+/* exFAST feature detector: replaces ExtendedFAST::detectImpl, sparsestereo/
+ * extendedfast.cpp:92-130 (FAST-9 at min_threshold :102, adaptive test and
+ * score :153-231, centre value extendedfast.h:18, non-maximum suppression
+ * fast9-inl.h:76-173).  Key points of all frames are written in raster order
+ * (kp_xy[2s], kp_xy[2s+1]) with kp_response[s] = score, or -1000 without
+ * SVX_EXFAST_NONMAX (.cpp:125); size 6 and angle -1 are constants of the
+ * reference (.cpp:116).  frame_offsets_host as for svx_high_gradient_points.
+ * SVX_EXFAST_THRESHOLD_ROUND_SAT reads cv::saturate_cast<char>(float) (.cpp:164)
+ * as round + saturate to [-128,127]; the default is the C++ conversion the
+ * generic template performs (truncation, low byte).  Synchronous. */
+enum svx_exfast_flags { SVX_EXFAST_NONMAX = 1, SVX_EXFAST_THRESHOLD_ROUND_SAT = 2 };
+int svx_exfast_detect(svx_ctx *ctx, const uint8_t *img, int rows, int cols, int n_frames, int min_threshold, float adaptivity,
+                      int flags, int32_t *kp_xy, float *kp_response, int capacity, int *frame_offsets_host);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------
  * Sustained issue rate, in lane-instructions per second, of the VALU pairs the
  * dense matcher is built from, with `waves_per_simd` wavefronts resident per

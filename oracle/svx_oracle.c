@@ -523,3 +523,272 @@ ORC_API void orc_census_nxn(const int8_t *in, int rows, int cols, int size, uint
                 }
         }
 }
+
+/* ===================== "next" rows: the steps either side of the path ===================== */
+
+/* ------------------------------------------------------------------ f4 --
+ * Pre-processing of highPerfStereo/highPerfStereoLib.cpp:245-280.  The
+ * arithmetic lives in OpenCV (not vendored, no version pinned), restated here
+ * from its documented behaviour: parity unpinned.
+ *
+ * equalizeHist (highPerfStereoLib.cpp:251-252): 256-bin histogram; i0 = first
+ * non-empty bin; if it holds every pixel the image becomes i0; else
+ * scale = 255.f/(total - hist[i0]), lut[i0] = 0 and for i > i0
+ * lut[i] = saturate_u8(round_half_even(float(sum_{k=i0+1..i} hist[k]) * scale)). */
+static int round_half_even_f(float v) { return (int)lrintf(v); }
+static uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+ORC_API void orc_equalize_hist(const uint8_t *src, uint8_t *dst, int rows, int cols) {
+    const long n = (long)rows * cols;
+    int hist[256] = {0};
+    for (long i = 0; i < n; ++i) hist[src[i]]++;
+    int i0 = 0;
+    while (i0 < 256 && !hist[i0]) ++i0;
+    if (i0 == 256) return;
+    if (hist[i0] == n) { for (long i = 0; i < n; ++i) dst[i] = (uint8_t)i0; return; }
+    uint8_t lut[256] = {0};
+    const float scale = 255.f / (float)(n - hist[i0]);
+    int sum = 0;
+    for (int i = i0 + 1; i < 256; ++i) { sum += hist[i]; lut[i] = sat_u8(round_half_even_f((float)sum * scale)); }
+    for (long i = 0; i < n; ++i) dst[i] = lut[src[i]];
+}
+
+/* Laplacian(ddepth = CV_16S, ksize 1 or 3, scale, delta, BORDER_REFLECT_101) followed by
+ * convertScaleAbs (highPerfStereoLib.cpp:258-259): kernel {0,1,0,1,-4,1,0,1,0} for ksize 1,
+ * {2,0,2,0,-8,0,2,0,2} for ksize 3; v = saturate_s16(round(sum*scale + delta)); out = saturate_u8(|v|). */
+static int refl101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; }
+ORC_API void orc_laplacian_abs(const uint8_t *src, uint8_t *dst, int rows, int cols, int ksize, double scale, double delta) {
+    static const int k1[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0}, k3[9] = {2, 0, 2, 0, -8, 0, 2, 0, 2};
+    const int *k = ksize == 1 ? k1 : k3;
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            int sum = 0;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx)
+                    sum += k[(dy + 1) * 3 + dx + 1] * (int)src[(long)refl101(y + dy, rows) * cols + refl101(x + dx, cols)];
+            long v = lrint((double)sum * scale + delta);
+            if (v < -32768) v = -32768;
+            if (v > 32767) v = 32767;
+            dst[(long)y * cols + x] = sat_u8((int)(v < 0 ? -v : v));
+        }
+}
+
+/* High-gradient point set, highPerfStereoLib.cpp:269-280: raster order over 2<=y<rows-2,
+ * 2<=x<cols-2, pixel > threshold.  Returns the count; pts_xy may be NULL to count only. */
+ORC_API int orc_high_gradient_points(const uint8_t *abs_grad, int rows, int cols, int threshold, int32_t *pts_xy) {
+    int n = 0;
+    for (int y = 2; y < rows - 2; ++y)
+        for (int x = 2; x < cols - 2; ++x)
+            if ((int)abs_grad[(long)y * cols + x] > threshold) {
+                if (pts_xy) { pts_xy[2 * n] = x; pts_xy[2 * n + 1] = y; }
+                ++n;
+            }
+    return n;
+}
+
+/* Crop to multiples of 16 from the top-left corner (highPerfStereoLib.cpp:245-247). dst is
+ * 16*(rows/16) x 16*(cols/16), densely packed. */
+ORC_API void orc_crop16(const uint8_t *src, int rows, int cols, uint8_t *dst) {
+    const int r2 = 16 * (rows / 16), c2 = 16 * (cols / 16);
+    for (int y = 0; y < r2; ++y) memcpy(dst + (long)y * c2, src + (long)y * cols, (size_t)c2);
+}
+
+/* GaussianBlur(img, img, Size(k,k), 0, 0) (highPerfStereoLib.cpp:289-292) for k in {1,3,5}: with
+ * sigma 0 OpenCV takes the binomial kernels {1}, {1,2,1}/4, {1,4,6,4,1}/16; all weights are
+ * dyadic, so the 8-bit result is the exact 2-D weighted sum rounded half up; BORDER_REFLECT_101.
+ * The reference passes blurSize = (int)applyBlur = 1 (highPerfStereoLib.cpp:207), i.e. a copy. */
+ORC_API void orc_gaussian_blur(const uint8_t *src, uint8_t *dst, int rows, int cols, int ksize) {
+    static const int w1[1] = {1}, w3[3] = {1, 2, 1}, w5[5] = {1, 4, 6, 4, 1};
+    const int *w = ksize == 1 ? w1 : (ksize == 3 ? w3 : w5);
+    const int h = ksize / 2, norm = ksize == 1 ? 1 : (ksize == 3 ? 16 : 256);
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            int sum = 0;
+            for (int dy = -h; dy <= h; ++dy)
+                for (int dx = -h; dx <= h; ++dx)
+                    sum += w[dy + h] * w[dx + h] * (int)src[(long)refl101(y + dy, rows) * cols + refl101(x + dx, cols)];
+            dst[(long)y * cols + x] = (uint8_t)((sum + norm / 2) / norm);
+        }
+}
+
+/* Row-band inversion and line tracing on the copies handed to the feature detector
+ * (highPerfStereoLib.cpp:300-335), in place.  Returns -1 where the reference would not terminate
+ * (nb_lines > rows makes its step 0). */
+ORC_API int orc_alter_rows(uint8_t *img, int rows, int cols, int invert_rows, int nb_rows, int trace_lines, int nb_lines, int line_size) {
+    if (invert_rows) {
+        if (nb_rows <= 0) return -1;
+        const int row_size = rows / nb_rows + 1;
+        const int nb = rows / row_size;
+        for (int i = 0; i < nb - 1; ++i)
+            if (i % 2 == 0)
+                for (long k = (long)i * row_size * cols; k < (long)(i + 1) * row_size * cols; ++k) img[k] = (uint8_t)(255 - img[k]);
+        if ((nb - 1) % 2 == 0)
+            for (long k = (long)(nb - 1) * row_size * cols; k < (long)rows * cols; ++k) img[k] = (uint8_t)(255 - img[k]);
+    }
+    if (trace_lines) {
+        if (nb_lines <= 0 || rows / nb_lines == 0) return -1;
+        const int step = rows / nb_lines;
+        for (int k = step / 2; k < rows; k += step)
+            for (int j = k; j < k + line_size && j < rows; ++j) memset(img + (long)j * cols, 0, (size_t)cols);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ f1 --
+ * exFAST feature detector, sparsestereo/extendedfast.cpp:92-231 with the centre value of
+ * extendedfast.h:18 and the sparse non-maximum suppression of fast9-inl.h:76-173.  The first
+ * stage, cv::FAST(image, corners, minThreshold, false) (extendedfast.cpp:102), lives in OpenCV
+ * (absent here): restated from its published definition (FAST-9 on the 16-pixel radius-3 circle,
+ * strict comparisons against centre +- threshold, 3-pixel border, raster order): parity unpinned.
+ *
+ * cv::saturate_cast<char>(float) (extendedfast.cpp:164) has no specialisation for plain char, so the
+ * generic template applies: a C++ float->char conversion, i.e. truncation toward zero, of which x86
+ * keeps the low byte.  round_sat != 0 selects the other reading (round half even, saturate to
+ * [-128,127]) for comparison. */
+static int arc9(unsigned m) {                      /* extendedfast.cpp:42-71 with the >=9 test of :34 */
+    int best = 0, start = -1, cur = 0;
+    for (int b = 0; b < 16; ++b) {
+        if (m & (1u << b)) ++cur;
+        else { if (cur > best) best = cur; if (start < 0) start = cur; cur = 0; }
+    }
+    if (start >= 0) cur += start;
+    if (cur > best) best = cur;
+    return best >= 9;
+}
+static const int CIRC_DX[16] = {-1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2};   /* extendedfast.cpp:73-90 */
+static const int CIRC_DY[16] = {-3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2};
+static int sat_s8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
+static int sat_u8i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+static int fast9_min(const uint8_t *img, int cols, int x, int y, int t) {
+    const int v = img[(long)y * cols + x];
+    unsigned br = 0, dk = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int p = img[(long)(y + CIRC_DY[i]) * cols + x + CIRC_DX[i]];
+        if (p > v + t) br |= 1u << i;
+        if (p < v - t) dk |= 1u << i;
+    }
+    return arc9(br) || arc9(dk);
+}
+
+/* extendedfast.cpp:153-175 and :177-231.  Returns 1 for a corner and stores its score. */
+static int exfast_test(const uint8_t *img, int cols, int x, int y, float adaptivity, int round_sat, uint8_t *score) {
+    int circ_u[16], circ_s[16], sum = 0, sad = 0;
+    for (int i = 0; i < 16; ++i) {
+        circ_u[i] = img[(long)(y + CIRC_DY[i]) * cols + x + CIRC_DX[i]];
+        circ_s[i] = (int)(int8_t)(uint8_t)(circ_u[i] - 128);
+        sum += circ_u[i];
+    }
+    const int avg = (int)(uint8_t)(sum / 16);
+    for (int i = 0; i < 16; ++i) sad += abs(circ_u[i] - avg);
+    const float tf = (float)sad * adaptivity / 16;
+    int thr_u;
+    if (round_sat) thr_u = (int)(uint8_t)(int8_t)sat_s8((int)lrintf(tf));
+    else thr_u = (int)tf & 0xff;
+    const int thr_s = (int)(int8_t)(uint8_t)thr_u;
+    const long c = (long)y * cols + x;
+    const int mean5 = ((int)img[c] + (int)img[c - cols] + (int)img[c + cols] + (int)img[c - 1] + (int)img[c + 1]) / 5;
+    const int cen_s = (int)(int8_t)(uint8_t)(mean5 - 128);
+    const int plus = sat_s8(cen_s + thr_s), minus = sat_s8(cen_s - thr_s);
+    unsigned br = 0, dk = 0;
+    for (int i = 0; i < 16; ++i) { if (circ_s[i] > plus) br |= 1u << i; if (minus > circ_s[i]) dk |= 1u << i; }
+    if (!arc9(br) && !arc9(dk)) return 0;
+    /* score: binary search between the threshold and 255 in the unsigned domain */
+    const int cen_u = (int)(uint8_t)(cen_s + 128);
+    int bmin = thr_u, bmax = 255, b = (bmax + bmin + 1) >> 1;
+    for (;;) {
+        const int cp = (int)(int8_t)(uint8_t)(sat_u8i(cen_u + b) - 128);
+        unsigned m = 0;
+        for (int i = 0; i < 16; ++i) if (circ_s[i] > cp) m |= 1u << i;
+        if (arc9(m)) bmin = b;
+        else {
+            const int cm = (int)(int8_t)(uint8_t)(sat_u8i(cen_u - b) - 128);
+            m = 0;
+            for (int i = 0; i < 16; ++i) if (cm > circ_s[i]) m |= 1u << i;
+            if (arc9(m)) bmin = b; else bmax = b;
+        }
+        if (bmin == bmax || bmin == bmax - 1) break;
+        b = (bmax + bmin + 1) >> 1;
+    }
+    *score = (uint8_t)(bmin - thr_u);
+    return 1;
+}
+
+/* Sparse non-maximum suppression over a raster-ordered corner list (fast9-inl.h:76-173): a corner
+ * is dropped when a listed 8-neighbour has a score >= its own.  Two cursors walk the rows above and
+ * below as the reference does.  keep[i] = 1 for survivors. */
+static void sparse_nonmax(const int32_t *xy, const uint8_t *score, int n, uint8_t *keep) {
+    if (n < 1) return;
+    const int last_row = xy[2 * (n - 1) + 1];
+    int *row_start = (int *)malloc(sizeof(int) * (size_t)(last_row + 1));
+    for (int r = 0; r <= last_row; ++r) row_start[r] = -1;
+    for (int i = 0, prev = -1; i < n; ++i) if (xy[2 * i + 1] != prev) { prev = xy[2 * i + 1]; row_start[prev] = i; }
+    int above = 0, below = 0;
+#define CX(i) xy[2 * (i)]
+#define CY(i) xy[2 * (i) + 1]
+    for (int i = 0; i < n; ++i) {
+        const int px = CX(i), py = CY(i), s = score[i];
+        keep[i] = 0;
+        if (i > 0 && CX(i - 1) == px - 1 && CY(i - 1) == py && score[i - 1] >= s) continue;
+        if (i < n - 1 && CX(i + 1) == px + 1 && CY(i + 1) == py && score[i + 1] >= s) continue;
+        int hit = 0;
+        if (py != 0 && row_start[py - 1] != -1) {
+            if (CY(above) < py - 1) above = row_start[py - 1];
+            while (CY(above) < py && CX(above) < px - 1) ++above;
+            for (int j = above; CY(j) < py && CX(j) <= px + 1; ++j)
+                if (CX(j) >= px - 1 && score[j] >= s) { hit = 1; break; }
+            if (hit) continue;
+        }
+        if (py != last_row && row_start[py + 1] != -1 && below < n) {
+            if (CY(below) < py + 1) below = row_start[py + 1];
+            while (below < n && CY(below) == py + 1 && CX(below) < px - 1) ++below;
+            for (int j = below; j < n && CY(j) == py + 1 && CX(j) <= px + 1; ++j)
+                if (CX(j) >= px - 1 && score[j] >= s) { hit = 1; break; }
+            if (hit) continue;
+        }
+        keep[i] = 1;
+    }
+#undef CX
+#undef CY
+    free(row_start);
+}
+
+/* Exported for the tests of the suppression rule itself. */
+ORC_API void orc_sparse_nonmax(const int32_t *xy, const uint8_t *score, int n, uint8_t *keep) { sparse_nonmax(xy, score, n, keep); }
+ORC_API int orc_arc9(unsigned mask16) { return arc9(mask16); }
+
+/* detectImpl, extendedfast.cpp:92-130.  Key points come out in raster order with response = score
+ * (nonmax) or -1000 (no nonmax); size 6 and angle -1 are constants of the reference and not stored.
+ * Returns the number found; at most `capacity` are written. */
+ORC_API int orc_exfast_detect(const uint8_t *img, int rows, int cols, int min_threshold, float adaptivity, int nonmax,
+                              int round_sat, int32_t *kp_xy, float *kp_response, int capacity) {
+    const long cap0 = (long)rows * cols;
+    int32_t *xy = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)(cap0 ? cap0 : 1));
+    uint8_t *sc = (uint8_t *)malloc((size_t)(cap0 ? cap0 : 1));
+    int n = 0;
+    const int t = min_threshold < 0 ? 0 : (min_threshold > 255 ? 255 : min_threshold);
+    for (int y = 3; y < rows - 3; ++y)
+        for (int x = 3; x < cols - 3; ++x) {
+            if (!fast9_min(img, cols, x, y, t)) continue;
+            uint8_t s = 0;
+            if (!exfast_test(img, cols, x, y, adaptivity, round_sat, &s)) continue;
+            xy[2 * n] = x; xy[2 * n + 1] = y; sc[n] = s; ++n;
+        }
+    int out = 0;
+    if (nonmax) {
+        uint8_t *keep = (uint8_t *)malloc((size_t)(n ? n : 1));
+        sparse_nonmax(xy, sc, n, keep);
+        for (int i = 0; i < n; ++i)
+            if (keep[i]) {
+                if (out < capacity) { kp_xy[2 * out] = xy[2 * i]; kp_xy[2 * out + 1] = xy[2 * i + 1]; kp_response[out] = (float)sc[i]; }
+                ++out;
+            }
+        free(keep);
+    } else {
+        for (int i = 0; i < n; ++i) {
+            if (out < capacity) { kp_xy[2 * out] = xy[2 * i]; kp_xy[2 * out + 1] = xy[2 * i + 1]; kp_response[out] = -1000.f; }
+            ++out;
+        }
+    }
+    free(xy); free(sc);
+    return out;
+}

@@ -15,10 +15,12 @@ from ._lib import (  # noqa: F401
     CENSUS_ZERO_REST,
     WINDOW_5X6,
     WINDOW_5X5,
+    EXFAST_NONMAX,
+    EXFAST_THRESHOLD_ROUND_SAT,
     EXPORTS,
     DOMINANT_KERNEL,
     dominant_kernel_timer,
 )
 
 __all__ = ["Context", "SvxError", "lib_path", "load_library", "CENSUS_SSE24", "CENSUS_GENERIC25",
-           "CENSUS_ZERO_REST", "WINDOW_5X6", "WINDOW_5X5", "EXPORTS"]
+           "CENSUS_ZERO_REST", "WINDOW_5X6", "WINDOW_5X5", "EXFAST_NONMAX", "EXFAST_THRESHOLD_ROUND_SAT", "EXPORTS"]

@@ -6,6 +6,7 @@ import os
 import numpy as np
 
 CENSUS_SSE24, CENSUS_GENERIC25, CENSUS_ZERO_REST = 0, 1, 16
+EXFAST_NONMAX, EXFAST_THRESHOLD_ROUND_SAT = 1, 2
 WINDOW_5X6, WINDOW_5X5 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -43,6 +44,13 @@ EXPORTS = {
     "svx_refine": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, C.c_uint, _vp, _vp] + [_vp] * 7),
     "svx_plane_fit": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
     "svx_plane_prior_raster": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "svx_crop16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "svx_equalize_hist": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "svx_laplacian_abs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_double, C.c_double]),
+    "svx_high_gradient_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "svx_gaussian_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "svx_alter_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "svx_exfast_detect": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, _i, _vp, _vp, _i, _vp]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
 }
 
@@ -309,6 +317,75 @@ class Context:
         self._call("svx_plane_prior_raster", _dptr(tri_xy), _dptr(tri_abc), tri_xy.shape[0], prior.shape[0], prior.shape[1],
                    _dptr(prior))
         return prior
+
+    # ---- pre-processing and feature detection (the steps before the census path) ----
+    def crop16(self, img):
+        t = self._torch
+        _check_dev(img, t.uint8, "img")
+        f, r, c = _frames(img)
+        shape = (16 * (r // 16), 16 * (c // 16))
+        out = t.empty(shape if img.dim() == 2 else (f,) + shape, dtype=t.uint8, device=img.device)
+        self._call("svx_crop16", _dptr(img), r, c, f, _dptr(out))
+        return out
+
+    def equalize_hist(self, img, out=None):
+        t = self._torch
+        _check_dev(img, t.uint8, "img")
+        f, r, c = _frames(img)
+        out = t.empty_like(img) if out is None else _check_dev(out, t.uint8, "out")
+        self._call("svx_equalize_hist", _dptr(img), _dptr(out), r, c, f)
+        return out
+
+    def laplacian_abs(self, img, ksize=3, scale=1.0, delta=0.0):
+        t = self._torch
+        _check_dev(img, t.uint8, "img")
+        f, r, c = _frames(img)
+        out = t.empty_like(img)
+        self._call("svx_laplacian_abs", _dptr(img), _dptr(out), r, c, f, int(ksize), float(scale), float(delta))
+        return out
+
+    def high_gradient_points(self, abs_grad, threshold, capacity=None):
+        """Returns (pts_xy [n,2] int32 device tensor, frame_offsets numpy int32 [frames+1])."""
+        t = self._torch
+        _check_dev(abs_grad, t.uint8, "abs_grad")
+        f, r, c = _frames(abs_grad)
+        capacity = f * r * c if capacity is None else int(capacity)
+        pts = t.empty((max(capacity, 1), 2), dtype=t.int32, device=abs_grad.device)
+        off = np.zeros(f + 1, np.int32)
+        self._call("svx_high_gradient_points", _dptr(abs_grad), r, c, f, int(threshold), _dptr(pts), capacity, off.ctypes.data_as(_vp))
+        return pts[:min(int(off[-1]), capacity)], off
+
+    def gaussian_blur(self, img, ksize):
+        t = self._torch
+        _check_dev(img, t.uint8, "img")
+        f, r, c = _frames(img)
+        out = t.empty_like(img)
+        self._call("svx_gaussian_blur", _dptr(img), _dptr(out), r, c, f, int(ksize))
+        return out
+
+    def alter_rows(self, img, invert_rows, nb_rows, trace_lines, nb_lines, line_size):
+        """In place."""
+        t = self._torch
+        _check_dev(img, t.uint8, "img")
+        f, r, c = _frames(img)
+        self._call("svx_alter_rows", _dptr(img), r, c, f, int(bool(invert_rows)), int(nb_rows), int(bool(trace_lines)),
+                   int(nb_lines), int(line_size))
+        return img
+
+    def exfast_detect(self, img, min_threshold, adaptivity, nonmax=True, flags=0, capacity=None):
+        """Returns (kp_xy [n,2] int32, response [n] float32) device tensors and frame_offsets (numpy int32 [frames+1])."""
+        t = self._torch
+        _check_dev(img, t.uint8, "img")
+        f, r, c = _frames(img)
+        capacity = f * r * c if capacity is None else int(capacity)
+        xy = t.empty((max(capacity, 1), 2), dtype=t.int32, device=img.device)
+        resp = t.empty(max(capacity, 1), dtype=t.float32, device=img.device)
+        off = np.zeros(f + 1, np.int32)
+        fl = int(flags) | (EXFAST_NONMAX if nonmax else 0)
+        self._call("svx_exfast_detect", _dptr(img), r, c, f, int(min_threshold), float(adaptivity), fl, _dptr(xy), _dptr(resp),
+                   capacity, off.ctypes.data_as(_vp))
+        n = min(int(off[-1]), capacity)
+        return xy[:n], resp[:n], off
 
 
 # ---- measurement helpers used by bench.py -------------------------------------------------------

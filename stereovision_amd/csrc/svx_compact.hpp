@@ -1,0 +1,121 @@
+// Raster-order stream compaction over a batch of frames (gfx950).
+//
+// A predicate pred(x, y, frame) selects pixels; the selected ones are handed to emit(slot, x, y, frame)
+// with slot = their rank in (frame, y, x) order, which is the order a sequential double loop over the
+// image pushes them into a vector.  Three launches: per-line counts, one-block exclusive scan over the
+// lines, per-line ranked write.  The predicate is evaluated twice, so it should be a cheap read.
+#pragma once
+#include "svx_common.hpp"
+
+namespace {          // one private copy per translation unit that includes this header
+
+template <class Pred>
+__global__ __launch_bounds__(256) void compact_count_kernel(Pred pred, int rows, int cols, unsigned *__restrict__ line_count) {
+    __shared__ unsigned wave_sum[4];
+    const int line = blockIdx.x, frame = line / rows, y = line - frame * rows;
+    unsigned c = 0;
+    for (int x = threadIdx.x; x < cols; x += 256) c += pred(x, y, frame) ? 1u : 0u;
+    for (int o = 32; o; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) line_count[line] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+// In-place exclusive scan of line_count[0..n_lines) by one block; line_count[n_lines] receives the total.
+__global__ __launch_bounds__(1024) void compact_scan_kernel(unsigned *__restrict__ line_count, int n_lines) {
+    __shared__ unsigned wave_tot[16];
+    __shared__ unsigned carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_lines; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned v = i < n_lines ? line_count[i] : 0u;
+        unsigned s = v;                                   // inclusive scan inside the wavefront
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(s, o, 64);
+            if (lane >= o) s += t;
+        }
+        if (lane == 63) wave_tot[wave] = s;
+        __syncthreads();
+        unsigned before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        if (i < n_lines) line_count[i] = before + s - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) line_count[n_lines] = carry;
+}
+
+template <class Pred, class Emit>
+__global__ __launch_bounds__(256) void compact_write_kernel(Pred pred, Emit emit, int rows, int cols,
+                                                            const unsigned *__restrict__ line_off, unsigned capacity) {
+    __shared__ unsigned wave_cnt[2][4];
+    const int line = blockIdx.x, frame = line / rows, y = line - frame * rows;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned base = line_off[line];
+    if (line_off[line + 1] == base) return;               // nothing selected on this line
+    int buf = 0;
+    for (int x0 = 0; x0 < cols; x0 += 256, buf ^= 1) {
+        const int x = x0 + threadIdx.x;
+        const bool f = x < cols && pred(x, y, frame);
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wave_cnt[buf][wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned before = 0, all = 0;
+        for (int w = 0; w < 4; ++w) {
+            const unsigned c = wave_cnt[buf][w];
+            before += w < wave ? c : 0u;
+            all += c;
+        }
+        if (f) {
+            const unsigned slot = base + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (slot < capacity) emit(slot, x, y, frame);
+        }
+        base += all;
+    }
+}
+
+__global__ void compact_frame_offsets_kernel(const unsigned *__restrict__ line_off, int rows, int n_frames, unsigned *__restrict__ frame_off) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f <= n_frames) frame_off[f] = line_off[(long)f * rows];
+}
+
+// Device bytes svx_compact_raster needs at `area`.
+static inline size_t svx_compact_bytes(int rows, int n_frames) {
+    return ((size_t)rows * n_frames + 1 + (size_t)n_frames + 1) * sizeof(unsigned);
+}
+
+// Runs the launches on the context's stream and returns the per-frame offsets
+// (frame_offsets_host[f] .. frame_offsets_host[f+1] are frame f's slots; n_frames+1 entries) after a
+// stream synchronisation.  Slots >= capacity are counted but not emitted.  `area` is device memory of
+// svx_compact_bytes(rows, n_frames) bytes that the caller reserved from the context's workspace.
+template <class Pred, class Emit>
+int svx_compact_raster(svx_ctx *ctx, void *area, int rows, int cols, int n_frames, Pred pred, Emit emit, int capacity,
+                       int *frame_offsets_host, const char *what) {
+    const long n_lines = (long)rows * n_frames;
+    if (n_lines > 0x7fffffffL / 2) return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "%s: too many image lines", what);
+    void *pin;
+    int rc = svx_pinned_reserve(ctx, (size_t)(n_frames + 1) * sizeof(unsigned), &pin);
+    if (rc) return rc;
+    unsigned *line_off = (unsigned *)area;
+    compact_count_kernel<Pred><<<(unsigned)n_lines, 256, 0, ctx->stream>>>(pred, rows, cols, line_off);
+    SVX_LAUNCH_CHECK(ctx, what);
+    compact_scan_kernel<<<1, 1024, 0, ctx->stream>>>(line_off, (int)n_lines);
+    SVX_LAUNCH_CHECK(ctx, what);
+    if (capacity > 0) {
+        compact_write_kernel<Pred, Emit><<<(unsigned)n_lines, 256, 0, ctx->stream>>>(pred, emit, rows, cols, line_off, (unsigned)capacity);
+        SVX_LAUNCH_CHECK(ctx, what);
+    }
+    // Frame f starts at line f*rows.
+    unsigned *frame_off = line_off + n_lines + 1;
+    compact_frame_offsets_kernel<<<svx_cdiv(n_frames + 1, 256), 256, 0, ctx->stream>>>(line_off, rows, n_frames, frame_off);
+    SVX_LAUNCH_CHECK(ctx, what);
+    SVX_HIP(ctx, hipMemcpyAsync(pin, frame_off, (size_t)(n_frames + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f <= n_frames; ++f) frame_offsets_host[f] = (int)((unsigned *)pin)[f];
+    return SVX_OK;
+}
+
+}  // namespace

@@ -47,6 +47,19 @@ lib.orc_census_nxn_words.argtypes = [C.c_int]
 lib.orc_u8_saturate_s8.argtypes = [_p, _p, C.c_size_t]
 lib.orc_census_nxn.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p]
 lib.orc_plane_prior_raster.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p]
+lib.orc_crop16.argtypes = [_p, C.c_int, C.c_int, _p]
+lib.orc_equalize_hist.argtypes = [_p, _p, C.c_int, C.c_int]
+lib.orc_laplacian_abs.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+lib.orc_high_gradient_points.restype = C.c_int
+lib.orc_high_gradient_points.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p]
+lib.orc_gaussian_blur.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int]
+lib.orc_alter_rows.restype = C.c_int
+lib.orc_alter_rows.argtypes = [_p] + [C.c_int] * 7
+lib.orc_sparse_nonmax.argtypes = [_p, _p, C.c_int, _p]
+lib.orc_arc9.restype = C.c_int
+lib.orc_arc9.argtypes = [C.c_uint]
+lib.orc_exfast_detect.restype = C.c_int
+lib.orc_exfast_detect.argtypes = [_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _p, _p, C.c_int]
 
 
 def _ptr(a):
@@ -174,6 +187,70 @@ def plane_prior_raster(tri_xy, tri_abc, rows, cols, prior):
     tri_abc = np.ascontiguousarray(tri_abc, dtype=np.float32).reshape(-1, 3)
     lib.orc_plane_prior_raster(_ptr(tri_xy), _ptr(tri_abc), len(tri_xy), rows, cols, _ptr(prior))
     return prior
+
+
+# ---- pre-processing and feature detection ----
+def crop16(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rows, cols = img.shape
+    out = np.empty((16 * (rows // 16), 16 * (cols // 16)), np.uint8)
+    lib.orc_crop16(_ptr(img), rows, cols, _ptr(out))
+    return out
+
+
+def equalize_hist(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = img.copy()
+    lib.orc_equalize_hist(_ptr(img), _ptr(out), img.shape[0], img.shape[1])
+    return out
+
+
+def laplacian_abs(img, ksize=3, scale=1.0, delta=0.0):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    lib.orc_laplacian_abs(_ptr(img), _ptr(out), img.shape[0], img.shape[1], ksize, scale, delta)
+    return out
+
+
+def high_gradient_points(abs_grad, threshold):
+    abs_grad = np.ascontiguousarray(abs_grad, dtype=np.uint8)
+    rows, cols = abs_grad.shape
+    n = lib.orc_high_gradient_points(_ptr(abs_grad), rows, cols, threshold, None)
+    pts = np.zeros((max(n, 1), 2), np.int32)
+    lib.orc_high_gradient_points(_ptr(abs_grad), rows, cols, threshold, _ptr(pts))
+    return pts[:n]
+
+
+def gaussian_blur(img, ksize):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    lib.orc_gaussian_blur(_ptr(img), _ptr(out), img.shape[0], img.shape[1], ksize)
+    return out
+
+
+def alter_rows(img, invert_rows, nb_rows, trace_lines, nb_lines, line_size):
+    out = np.ascontiguousarray(img, dtype=np.uint8).copy()
+    rc = lib.orc_alter_rows(_ptr(out), out.shape[0], out.shape[1], int(invert_rows), nb_rows, int(trace_lines), nb_lines, line_size)
+    assert rc == 0
+    return out
+
+
+def sparse_nonmax(xy, score):
+    xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+    score = np.ascontiguousarray(score, dtype=np.uint8)
+    keep = np.zeros(max(len(xy), 1), np.uint8)
+    lib.orc_sparse_nonmax(_ptr(xy), _ptr(score), len(xy), _ptr(keep))
+    return keep[:len(xy)].astype(bool)
+
+
+def exfast_detect(img, min_threshold, adaptivity, nonmax=True, round_sat=False):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rows, cols = img.shape
+    cap = rows * cols
+    xy = np.zeros((cap, 2), np.int32)
+    resp = np.zeros(cap, np.float32)
+    n = lib.orc_exfast_detect(_ptr(img), rows, cols, min_threshold, adaptivity, int(nonmax), int(round_sat), _ptr(xy), _ptr(resp), cap)
+    return xy[:n].copy(), resp[:n].copy()
 
 
 # ---- the formula image of tests/golden/survey_kat.json ----

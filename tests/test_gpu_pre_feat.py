@@ -1,0 +1,195 @@
+"""GPU parity tests of the steps either side of the census path (pre-processing and the exFAST
+detector), through the C ABI, bit-exact against the CPU oracle.  The oracle's versions of the OpenCV
+calls (equalizeHist, Laplacian, convertScaleAbs, GaussianBlur, FAST) restate documented behaviour and
+are not pinned on reference outputs: parity unpinned for those, pinned GPU == oracle only."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import stereovision_amd as S
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    c = S.Context(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def textured(rng, rows, cols, blocks=True):
+    """Piecewise-constant blocks + ramps + noise: plenty of corners and large ring contrasts."""
+    y, x = np.mgrid[0:rows, 0:cols]
+    img = (x * 3 + y * 5) % 256
+    if blocks:
+        img = np.where(((x // 7) + (y // 5)) % 2 == 0, img, 255 - img)
+        img = np.where(((x // 23) + (y // 17)) % 3 == 0, (img // 128) * 255, img)
+    img = img + rng.integers(-12, 13, size=(rows, cols))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+SHAPES = [(375, 1242), (64, 64), (37, 129), (16, 16), (7, 7), (6, 40), (5, 5), (1, 1), (3, 300)]
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+def test_crop16(ctx, rows, cols):
+    rng = np.random.default_rng(rows + cols)
+    img = rng.integers(0, 256, size=(2, rows, cols), dtype=np.uint8)
+    if rows < 16 or cols < 16:
+        import stereovision_amd as S
+        with pytest.raises(S.SvxError):
+            ctx.crop16(dev(img))
+        return
+    got = ctx.crop16(dev(img)).cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(got[f], O.crop16(img[f]))
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+def test_equalize_hist(ctx, rows, cols):
+    rng = np.random.default_rng(rows * 7 + cols)
+    frames = [textured(rng, rows, cols), rng.integers(40, 90, size=(rows, cols), dtype=np.uint8),
+              np.full((rows, cols), 77, np.uint8), rng.integers(0, 2, size=(rows, cols), dtype=np.uint8) * 255]
+    batch = np.stack(frames)
+    got = ctx.equalize_hist(dev(batch)).cpu().numpy()
+    for f in range(len(frames)):
+        assert np.array_equal(got[f], O.equalize_hist(frames[f])), f
+    # in place, as the reference calls it (highPerfStereoLib.cpp:251)
+    d = dev(frames[0])
+    ctx.equalize_hist(d, out=d)
+    assert np.array_equal(d.cpu().numpy(), O.equalize_hist(frames[0]))
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+@pytest.mark.parametrize("ksize,scale,delta", [(3, 1, 0), (1, 1, 0), (3, 2, -7), (1, 0.5, 3), (3, 40, 0)])
+def test_laplacian_abs(ctx, rows, cols, ksize, scale, delta):
+    rng = np.random.default_rng(rows * 3 + cols + ksize)
+    batch = np.stack([textured(rng, rows, cols), rng.integers(0, 256, size=(rows, cols), dtype=np.uint8)])
+    got = ctx.laplacian_abs(dev(batch), ksize, scale, delta).cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(got[f], O.laplacian_abs(batch[f], ksize, scale, delta))
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+@pytest.mark.parametrize("threshold", [0, 50, 200, 255])
+def test_high_gradient_points(ctx, rows, cols, threshold):
+    rng = np.random.default_rng(rows + 31 * cols + threshold)
+    batch = np.stack([O.laplacian_abs(textured(rng, rows, cols)), rng.integers(0, 256, size=(rows, cols), dtype=np.uint8),
+                      np.zeros((rows, cols), np.uint8)])
+    pts, off = ctx.high_gradient_points(dev(batch), threshold)
+    pts = pts.cpu().numpy()
+    assert off[0] == 0 and len(pts) == off[-1]
+    for f in range(3):
+        want = O.high_gradient_points(batch[f], threshold)
+        assert off[f + 1] - off[f] == len(want)
+        assert np.array_equal(pts[off[f]:off[f + 1]], want)
+
+
+def test_high_gradient_points_capacity(ctx):
+    rng = np.random.default_rng(9)
+    g = rng.integers(0, 256, size=(40, 50), dtype=np.uint8)
+    want = O.high_gradient_points(g, 100)
+    pts, off = ctx.high_gradient_points(dev(g), 100, capacity=17)
+    assert off[-1] == len(want) and len(pts) == 17
+    assert np.array_equal(pts.cpu().numpy(), want[:17])
+    pts, off = ctx.high_gradient_points(dev(g), 100, capacity=0)
+    assert off[-1] == len(want)
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+@pytest.mark.parametrize("ksize", [1, 3, 5])
+def test_gaussian_blur(ctx, rows, cols, ksize):
+    rng = np.random.default_rng(rows + cols * 5 + ksize)
+    batch = np.stack([textured(rng, rows, cols), rng.integers(0, 256, size=(rows, cols), dtype=np.uint8)])
+    got = ctx.gaussian_blur(dev(batch), ksize).cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(got[f], O.gaussian_blur(batch[f], ksize))
+
+
+@pytest.mark.parametrize("rows,cols", [(368, 1232), (64, 64), (37, 129), (16, 16), (7, 7), (1, 1)])
+@pytest.mark.parametrize("params", [(True, 10, True, 20, 2), (True, 1, False, 1, 1), (False, 3, True, 5, 9), (True, 7, True, 1, 400),
+                                    (True, 400, True, 3, 1), (True, 2, False, 1, 1), (False, 1, False, 1, 1)])
+def test_alter_rows(ctx, rows, cols, params):
+    inv, nb_rows, trace, nb_lines, line_size = params
+    if trace and rows // nb_lines == 0:
+        import stereovision_amd as S
+        with pytest.raises(S.SvxError):
+            ctx.alter_rows(dev(np.zeros((rows, cols), np.uint8)), *params)
+        return
+    rng = np.random.default_rng(rows + cols)
+    batch = rng.integers(0, 256, size=(2, rows, cols), dtype=np.uint8)
+    got = ctx.alter_rows(dev(batch), *params).cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(got[f], O.alter_rows(batch[f], *params))
+
+
+# ------------------------------------------------------------------ exFAST
+@pytest.mark.parametrize("rows,cols", [(375, 1242), (368, 1232), (64, 64), (37, 129), (16, 70), (8, 8), (7, 7), (6, 40), (3, 3)])
+@pytest.mark.parametrize("min_threshold,adaptivity", [(10, 1.0), (0, 0.5), (25, 2.5), (3, 0.25)])
+def test_exfast_matches_oracle(ctx, rows, cols, min_threshold, adaptivity):
+    rng = np.random.default_rng(rows * 13 + cols + min_threshold)
+    frames = [textured(rng, rows, cols), textured(rng, rows, cols, blocks=False),
+              rng.integers(0, 256, size=(rows, cols), dtype=np.uint8)]
+    batch = np.stack(frames)
+    for nonmax in (True, False):
+        xy, resp, off = ctx.exfast_detect(dev(batch), min_threshold, adaptivity, nonmax=nonmax)
+        xy, resp = xy.cpu().numpy(), resp.cpu().numpy()
+        assert off[0] == 0 and off[-1] == len(xy)
+        for f in range(len(frames)):
+            wxy, wresp = O.exfast_detect(frames[f], min_threshold, adaptivity, nonmax)
+            assert off[f + 1] - off[f] == len(wxy), (f, nonmax)
+            assert np.array_equal(xy[off[f]:off[f + 1]], wxy)
+            assert np.array_equal(resp[off[f]:off[f + 1]], wresp)
+
+
+def test_exfast_finds_corners_and_threshold_readings(ctx):
+    import stereovision_amd as S
+    rng = np.random.default_rng(77)
+    img = textured(rng, 120, 200)
+    wxy, wresp = O.exfast_detect(img, 10, 1.0, True)
+    assert len(wxy) > 50                                    # the test is not vacuous
+    wxy2, wresp2 = O.exfast_detect(img, 10, 1.0, True, round_sat=True)
+    xy, resp, off = ctx.exfast_detect(dev(img), 10, 1.0, nonmax=True, flags=S.EXFAST_THRESHOLD_ROUND_SAT)
+    assert np.array_equal(xy.cpu().numpy(), wxy2) and np.array_equal(resp.cpu().numpy(), wresp2)
+    xy, resp, off = ctx.exfast_detect(dev(img), 10, 1.0, nonmax=True)
+    assert np.array_equal(xy.cpu().numpy(), wxy) and np.array_equal(resp.cpu().numpy(), wresp)
+
+
+def test_exfast_capacity_and_errors(ctx):
+    import stereovision_amd as S
+    rng = np.random.default_rng(5)
+    img = textured(rng, 60, 90)
+    wxy, wresp = O.exfast_detect(img, 10, 1.0, True)
+    xy, resp, off = ctx.exfast_detect(dev(img), 10, 1.0, capacity=5)
+    assert off[-1] == len(wxy) and np.array_equal(xy.cpu().numpy(), wxy[:5]) and np.array_equal(resp.cpu().numpy(), wresp[:5])
+    with pytest.raises(S.SvxError):
+        ctx.exfast_detect(dev(img), 10, 1.0, flags=64)
+
+
+def test_detector_feeds_sparse_matcher(ctx):
+    """exFAST key points (left with, right without suppression: highPerfStereoLib.cpp:358-359) through the
+    sparse matcher give the same correspondences on the GPU path and in the oracle."""
+    from stereovision_amd import synth
+    import stereovision_amd as S
+    left, right = synth.stereo_pair(96, 320, 32, seed=11)[:2]
+    lxy, _, _ = ctx.exfast_detect(dev(left), 10, 1.0, nonmax=True)
+    rxy, _, _ = ctx.exfast_detect(dev(right), 10, 1.0, nonmax=False)
+    wl, _ = O.exfast_detect(left, 10, 1.0, True)
+    wr, _ = O.exfast_detect(right, 10, 1.0, False)
+    assert np.array_equal(lxy.cpu().numpy(), wl) and np.array_equal(rxy.cpu().numpy(), wr)
+    cl = ctx.census5x5(dev(left), S.CENSUS_SSE24 | S.CENSUS_ZERO_REST)
+    cr = ctx.census5x5(dev(right), S.CENSUS_SSE24 | S.CENSUS_ZERO_REST)
+    got = ctx.sparse_match(cl, cr, lxy.cpu().numpy().astype(np.float32), rxy.cpu().numpy().astype(np.float32), 32)
+    ocl = O.census5x5(O.u8_to_s8(left)); ocr = O.census5x5(O.u8_to_s8(right))
+    want = O.sparse_match(ocl, ocr, wl.astype(np.float32), wr.astype(np.float32), 32)
+    assert len(want[0]) > 10
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
