@@ -233,6 +233,32 @@ enum svx_exfast_flags { SVX_EXFAST_NONMAX = 1, SVX_EXFAST_THRESHOLD_ROUND_SAT = 
 int svx_exfast_detect(svx_ctx *ctx, const uint8_t *img, int rows, int cols, int n_frames, int min_threshold, float adaptivity,
                       int flags, int32_t *kp_xy, float *kp_response, int capacity, int *frame_offsets_host);
 
+/* Support-point mesh: stands in for the Fade_2D triangulation of highPerfStereoLib.cpp:434-445
+ * (insert) and :457 (getTrianglePointers).  Fade2D is a closed library outside the reference
+ * tree; the mesh built here satisfies the Delaunay property exactly (integer predicates) and is
+ * unique unless four points are cocircular, where the diagonal chosen may differ from Fade2D's.
+ * svx_delaunay (host in, host out): triangles as index triples into pts_xy_host, every triple
+ *   rotated to lead with its smallest index, the list sorted lexicographically; repeated
+ *   positions are represented by their first index; all-collinear input gives no triangle;
+ *   *n_tri is the number found, at most `capacity` are stored.  Touches no device: ctx may be
+ *   NULL.
+ * svx_mesh_plane_prior: triangulation, plane table (.cpp:454-466) and interpolation loop
+ *   (.cpp:532-554) in one call: host support points, device disparities, device prior. */
+int svx_delaunay(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, int32_t *tri_idx_host, int capacity, int *n_tri);
+int svx_mesh_plane_prior(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, const float *disparities, int rows, int cols,
+                         float *prior, int *n_tri_out);
+
+/* Point cloud: replaces the reprojection loop of highPerfStereo/highPerfStereo.cpp:689-723
+ * (cv::perspectiveTransform of (x+roi_x, y+roi_y, disparity(y,x)) by the 4x4 double matrix Q,
+ * row-major in q_host; keep when z > 0 and sqrt(x^2+y^2+z^2) < max_range, 8000 in the
+ * reference).  pts_xy (device) are positions in the disparity map, e.g. the high-gradient list;
+ * kept points are written in input order: xyz_out[3s..] doubles and, when rgb_out is given,
+ * r,g,b bytes read from the 3-channel BGR image `bgr` ([img_rows][img_cols][3], device) at the
+ * ROI-shifted position.  *n_out_host = number kept; at most `capacity` are stored.  Synchronous. */
+int svx_point_cloud(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float *disparity_map, int rows, int cols,
+                    int roi_x, int roi_y, const double *q_host, const uint8_t *bgr, int img_rows, int img_cols,
+                    double max_range, double *xyz_out, uint8_t *rgb_out, int capacity, int *n_out_host);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------
  * Sustained issue rate, in lane-instructions per second, of the VALU pairs the
  * dense matcher is built from, with `waves_per_simd` wavefronts resident per

@@ -31,6 +31,7 @@
 #include <string.h>
 #include <math.h>
 #include <limits.h>
+#include <float.h>
 
 #define ORC_API __attribute__((visibility("default")))
 
@@ -790,5 +791,131 @@ ORC_API int orc_exfast_detect(const uint8_t *img, int rows, int cols, int min_th
         }
     }
     free(xy); free(sc);
+    return out;
+}
+
+/* ------------------------------------------------------------------ f2 --
+ * Support-point mesh.  The reference triangulates with Fade_2D (highPerfStereoLib.cpp:434-445,
+ * :457), a closed library that is not part of the reference tree: there is no algorithm to restate
+ * and no output to pin on, parity unpinned.  What can be checked is the definition of a Delaunay
+ * triangulation, done here by brute force with exact integer predicates.
+ *
+ * orc_delaunay_check returns 0 when `tri` (index triples into pts) is a Delaunay triangulation of
+ * the distinct positions in pts, else a positive code:
+ *   1 index out of range / repeated vertex   2 degenerate triangle
+ *   3 a point strictly inside a circumcircle 4 a directed edge used twice / unmatched inner edge
+ *   5 triangle areas do not add up to the hull area   6 a point is no vertex although triangles exist
+ */
+typedef __int128 orc_i128;
+static long long orient2(const int32_t *p, int a, int b, int c) {
+    return (long long)(p[2 * b] - p[2 * a]) * (p[2 * c + 1] - p[2 * a + 1]) - (long long)(p[2 * b + 1] - p[2 * a + 1]) * (p[2 * c] - p[2 * a]);
+}
+static int incircle_sign(const int32_t *p, int a, int b, int c, int d) {   /* a,b,c counter-clockwise */
+    const long long ax = p[2 * a] - p[2 * d], ay = p[2 * a + 1] - p[2 * d + 1], bx = p[2 * b] - p[2 * d], by = p[2 * b + 1] - p[2 * d + 1];
+    const long long cx = p[2 * c] - p[2 * d], cy = p[2 * c + 1] - p[2 * d + 1];
+    const orc_i128 a2 = (orc_i128)ax * ax + (orc_i128)ay * ay, b2 = (orc_i128)bx * bx + (orc_i128)by * by, c2 = (orc_i128)cx * cx + (orc_i128)cy * cy;
+    const orc_i128 det = a2 * ((orc_i128)bx * cy - (orc_i128)by * cx) - b2 * ((orc_i128)ax * cy - (orc_i128)ay * cx) + c2 * ((orc_i128)ax * by - (orc_i128)ay * bx);
+    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+}
+static const int32_t *g_sort_pts;
+static int cmp_pt_idx(const void *a, const void *b) {
+    const int i = *(const int *)a, j = *(const int *)b;
+    if (g_sort_pts[2 * i] != g_sort_pts[2 * j]) return g_sort_pts[2 * i] < g_sort_pts[2 * j] ? -1 : 1;
+    if (g_sort_pts[2 * i + 1] != g_sort_pts[2 * j + 1]) return g_sort_pts[2 * i + 1] < g_sort_pts[2 * j + 1] ? -1 : 1;
+    return i < j ? -1 : (i > j);
+}
+static int cmp_edge(const void *a, const void *b) {
+    const long long x = *(const long long *)a, y = *(const long long *)b;
+    return x < y ? -1 : (x > y);
+}
+ORC_API int orc_delaunay_check(const int32_t *pts, int n, const int32_t *tri, int nt) {
+    long long area2 = 0;
+    /* canonical representative of each position: the first index holding it */
+    int *order = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1)), *canon = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+    for (int i = 0; i < n; ++i) order[i] = i;
+    g_sort_pts = pts;
+    qsort(order, (size_t)n, sizeof(int), cmp_pt_idx);
+    for (int i = 0; i < n; ++i)
+        canon[order[i]] = (i > 0 && pts[2 * order[i]] == pts[2 * order[i - 1]] && pts[2 * order[i] + 1] == pts[2 * order[i - 1] + 1]) ? canon[order[i - 1]] : order[i];
+    int rc = 0;
+    uint8_t *used = (uint8_t *)calloc((size_t)(n ? n : 1), 1);
+    long long *edges = (long long *)malloc(sizeof(long long) * 3 * (size_t)(nt ? nt : 1));
+    for (int t = 0; t < nt && !rc; ++t) {
+        const int a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+        if (a < 0 || b < 0 || c < 0 || a >= n || b >= n || c >= n || a == b || b == c || a == c) { rc = 1; break; }
+        const long long o = orient2(pts, a, b, c);
+        if (o == 0) { rc = 2; break; }
+        area2 += o < 0 ? -o : o;
+        used[canon[a]] = used[canon[b]] = used[canon[c]] = 1;
+        const int v[3] = {canon[a], o > 0 ? canon[b] : canon[c], o > 0 ? canon[c] : canon[b]};   /* counter-clockwise */
+        for (int k = 0; k < 3; ++k) edges[3 * t + k] = (long long)v[k] * n + v[(k + 1) % 3];
+        for (int d = 0; d < n; ++d)
+            if (incircle_sign(pts, v[0], v[1], v[2], d) > 0) { rc = 3; break; }
+    }
+    /* hull of the distinct positions (monotone chain, collinear points dropped) and its doubled area */
+    long long hull2 = 0;
+    int n_hull_edges = 0;
+    if (!rc) {
+        int *h = (int *)malloc(sizeof(int) * (size_t)(2 * n + 2));
+        int m = 0, nu = 0;
+        int *u = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+        for (int i = 0; i < n; ++i) if (canon[order[i]] == order[i]) u[nu++] = order[i];
+        for (int i = 0; i < nu; ++i) { while (m >= 2 && orient2(pts, h[m - 2], h[m - 1], u[i]) <= 0) --m; h[m++] = u[i]; }
+        for (int i = nu - 2, lo = m + 1; i >= 0; --i) { while (m >= lo && orient2(pts, h[m - 2], h[m - 1], u[i]) <= 0) --m; h[m++] = u[i]; }
+        if (m > 1) --m;
+        for (int i = 1; i + 1 < m; ++i) hull2 += orient2(pts, h[0], h[i], h[i + 1]);
+        if (nt > 0) for (int i = 0; i < nu; ++i) if (!used[u[i]]) rc = 6;
+        if (!rc && hull2 != area2) rc = 5;
+        if (!rc && nt == 0 && hull2 != 0) rc = 5;
+        free(h); free(u);
+    }
+    if (!rc && nt > 0) {
+        qsort(edges, (size_t)(3 * nt), sizeof(long long), cmp_edge);
+        for (int i = 1; i < 3 * nt; ++i) if (edges[i] == edges[i - 1]) { rc = 4; break; }
+        /* every directed edge without its reverse is a boundary edge; a triangulation of a convex region has
+         * as many of those as the hull polygon has (possibly split) sides, and they must enclose hull2 */
+        for (int i = 0; i < 3 * nt && !rc; ++i) {
+            const long long a = edges[i] / n, b = edges[i] % n, rev = b * n + a;
+            if (!bsearch(&rev, edges, (size_t)(3 * nt), sizeof(long long), cmp_edge)) ++n_hull_edges;
+        }
+        /* Euler: for a triangulated disc, 3*nt = 2*E - B and V - E + nt = 1 */
+        int nv = 0;
+        for (int i = 0; i < n; ++i) nv += used[i];
+        const long long E = (3LL * nt + n_hull_edges) / 2;
+        if (!rc && ((3LL * nt + n_hull_edges) % 2 != 0 || nv - E + nt != 1)) rc = 4;
+    }
+    free(order); free(canon); free(used); free(edges);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ f3 --
+ * Point cloud, highPerfStereo/highPerfStereo.cpp:689-723.  cv::perspectiveTransform (OpenCV, absent)
+ * restated from its documented formula for 3-channel double input and a 4x4 matrix:
+ * w = m12 x + m13 y + m14 z + m15; if |w| > FLT_EPSILON the result is the first three rows times
+ * 1/w, else 0.  Parity unpinned.  A point is kept when z > 0 and sqrt(x^2+y^2+z^2) < max_range
+ * (:720); colours are read at the ROI-shifted position in r,g,b order (:715-718).
+ * Returns the number kept. */
+ORC_API int orc_point_cloud(const int32_t *pts_xy, int n, const float *disp, int cols, int roi_x, int roi_y, const double *q,
+                            const uint8_t *bgr, int img_cols, double max_range, double *xyz, uint8_t *rgb) {
+    int out = 0;
+    for (int i = 0; i < n; ++i) {
+        const int px = pts_xy[2 * i], py = pts_xy[2 * i + 1];
+        const double x = px + roi_x, y = py + roi_y, z = (double)disp[(long)py * cols + px];
+        double w = x * q[12] + y * q[13] + z * q[14] + q[15], X = 0, Y = 0, Z = 0;
+        if (fabs(w) > (double)FLT_EPSILON) {
+            w = 1. / w;
+            X = (x * q[0] + y * q[1] + z * q[2] + q[3]) * w;
+            Y = (x * q[4] + y * q[5] + z * q[6] + q[7]) * w;
+            Z = (x * q[8] + y * q[9] + z * q[10] + q[11]) * w;
+        }
+        if (Z > 0 && sqrt(pow(X, 2) + pow(Y, 2) + pow(Z, 2)) < max_range) {
+            xyz[3 * out] = X; xyz[3 * out + 1] = Y; xyz[3 * out + 2] = Z;
+            if (rgb) {
+                const uint8_t *c = bgr + 3 * ((long)(py + roi_y) * img_cols + px + roi_x);
+                rgb[3 * out] = c[2]; rgb[3 * out + 1] = c[1]; rgb[3 * out + 2] = c[0];
+            }
+            ++out;
+        }
+    }
     return out;
 }

@@ -20,6 +20,7 @@ from ._lib import (  # noqa: F401
     EXPORTS,
     DOMINANT_KERNEL,
     dominant_kernel_timer,
+    delaunay,
 )
 
 __all__ = ["Context", "SvxError", "lib_path", "load_library", "CENSUS_SSE24", "CENSUS_GENERIC25",

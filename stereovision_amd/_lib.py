@@ -51,6 +51,9 @@ EXPORTS = {
     "svx_gaussian_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "svx_alter_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i]),
     "svx_exfast_detect": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, _i, _vp, _vp, _i, _vp]),
+    "svx_delaunay": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]),
+    "svx_mesh_plane_prior": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_i)]),
+    "svx_point_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
 }
 
@@ -386,6 +389,55 @@ class Context:
                    capacity, off.ctypes.data_as(_vp))
         n = min(int(off[-1]), capacity)
         return xy[:n], resp[:n], off
+
+    # ---- support-point mesh ----
+    def delaunay(self, pts_xy):
+        """Host in, host out: [n_tri, 3] int32 index triples."""
+        return delaunay(pts_xy)
+
+    def mesh_plane_prior(self, pts_xy, disparities, prior):
+        t = self._torch
+        _check_dev(disparities, t.float32, "disparities"); _check_dev(prior, t.float32, "prior")
+        pts = np.ascontiguousarray(pts_xy, dtype=np.int32).reshape(-1, 2)
+        n = _i(0)
+        self._call("svx_mesh_plane_prior", pts.ctypes.data_as(_vp), len(pts), _dptr(disparities), disparities.shape[0],
+                   disparities.shape[1], _dptr(prior), C.byref(n))
+        return prior, n.value
+
+    # ---- point cloud ----
+    def point_cloud(self, pts_xy, disparity_map, q, roi=(0, 0), bgr=None, max_range=8000.0, capacity=None):
+        """Returns (xyz [n,3] float64, rgb [n,3] uint8 or None) device tensors of the kept points, in input order."""
+        t = self._torch
+        _check_dev(pts_xy, t.int32, "pts_xy"); _check_dev(disparity_map, t.float32, "disparity_map")
+        n = pts_xy.shape[0]
+        capacity = n if capacity is None else int(capacity)
+        qh = np.ascontiguousarray(q, dtype=np.float64).reshape(16)
+        xyz = t.empty((max(capacity, 1), 3), dtype=t.float64, device=pts_xy.device)
+        rgb = None
+        ir = ic = 0
+        if bgr is not None:
+            _check_dev(bgr, t.uint8, "bgr")
+            ir, ic = bgr.shape[0], bgr.shape[1]
+            rgb = t.empty((max(capacity, 1), 3), dtype=t.uint8, device=pts_xy.device)
+        k = _i(0)
+        self._call("svx_point_cloud", _dptr(pts_xy), n, _dptr(disparity_map), disparity_map.shape[0], disparity_map.shape[1],
+                   int(roi[0]), int(roi[1]), qh.ctypes.data_as(_vp), _dptr(bgr) if bgr is not None else None, ir, ic,
+                   float(max_range), _dptr(xyz), _dptr(rgb) if rgb is not None else None, capacity, C.byref(k))
+        m = min(k.value, capacity)
+        return xyz[:m], (rgb[:m] if rgb is not None else None), k.value
+
+
+def delaunay(pts_xy):
+    """Host-only triangulation (no device, no context): [n_tri, 3] int32 index triples into pts_xy."""
+    lib = load_library()
+    pts = np.ascontiguousarray(pts_xy, dtype=np.int32).reshape(-1, 2)
+    cap = max(2 * len(pts), 1)
+    tri = np.zeros((cap, 3), np.int32)
+    n = _i(0)
+    rc = lib.svx_delaunay(None, pts.ctypes.data_as(_vp), len(pts), tri.ctypes.data_as(_vp), cap, C.byref(n))
+    if rc != 0:
+        raise SvxError(rc, lib.svx_strerror(rc).decode())
+    return tri[:n.value].copy()
 
 
 # ---- measurement helpers used by bench.py -------------------------------------------------------

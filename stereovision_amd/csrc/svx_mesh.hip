@@ -1,0 +1,249 @@
+// Support-point mesh: a host-side Delaunay triangulation of integer pixel positions feeding the
+// device plane fit and rasteriser.  It takes the place of the Fade_2D object of
+// highPerfStereo/highPerfStereoLib.cpp:434-445 (insert) and :457 (getTrianglePointers); Fade2D is a
+// closed library, so only the defining property is reproduced: no point lies strictly inside a
+// triangle's circumcircle.  Where four or more points are cocircular the diagonal is a free choice and
+// may differ from Fade2D's.
+//
+// Construction: points sorted by (x, y) are added one at a time; each new point lies outside the hull
+// built so far and is joined to every hull edge it sees, then the new edges are legalised by flips.
+// All predicates are exact (64/128-bit integers; coordinates must fit in 24 bits).
+#include "svx_common.hpp"
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+typedef long long i64;
+typedef __int128 i128;
+
+struct Pt { i64 x, y; int id; };
+
+inline i64 orient(const Pt &a, const Pt &b, const Pt &c) { return (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x); }
+
+// > 0 when d lies strictly inside the circle through a, b, c (a, b, c counter-clockwise).
+inline int in_circle(const Pt &a, const Pt &b, const Pt &c, const Pt &d) {
+    const i64 ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+    const i128 a2 = (i128)ax * ax + (i128)ay * ay, b2 = (i128)bx * bx + (i128)by * by, c2 = (i128)cx * cx + (i128)cy * cy;
+    const i128 det = a2 * ((i128)bx * cy - (i128)by * cx) - b2 * ((i128)ax * cy - (i128)ay * cx) + c2 * ((i128)ax * by - (i128)ay * bx);
+    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+}
+
+struct Tri { int v[3]; int n[3]; };      // n[i]: triangle across the edge opposite v[i], -1 on the hull
+
+class Delaunay {
+public:
+    std::vector<Pt> p;                   // unique points in (x, y) order
+    std::vector<Tri> t;
+
+    void build() {
+        const int n = (int)p.size();
+        next_.assign(n, -1); prev_.assign(n, -1); hull_tri_.assign(n, -1);
+        if (n < 3) return;
+        int k = 2;                       // p[0..k) is the leading collinear run
+        while (k < n && orient(p[0], p[1], p[k]) == 0) ++k;
+        if (k == n) return;              // every point on one line: no triangle
+        seed(k);
+        for (int i = k + 1; i < n; ++i) add_outside(i, i - 1);
+    }
+
+private:
+    std::vector<int> next_, prev_, hull_tri_;    // counter-clockwise hull; hull_tri_[u] owns edge u -> next_[u]
+    std::vector<std::pair<int, int>> stack_;
+
+    int new_tri(int a, int b, int c) {
+        Tri x; x.v[0] = a; x.v[1] = b; x.v[2] = c; x.n[0] = x.n[1] = x.n[2] = -1;
+        t.push_back(x);
+        return (int)t.size() - 1;
+    }
+    static int slot_of_vertex(const Tri &x, int v) { return x.v[0] == v ? 0 : (x.v[1] == v ? 1 : 2); }
+    static int slot_of_neighbour(const Tri &x, int nb) { return x.n[0] == nb ? 0 : (x.n[1] == nb ? 1 : 2); }
+
+    // Fan from point k over the collinear run 0..k-1.
+    void seed(int k) {
+        const bool left = orient(p[0], p[k - 1], p[k]) > 0;      // k lies to the left of the run's direction
+        int prev_tri = -1;
+        for (int i = 0; i + 1 < k; ++i) {
+            const int a = left ? i : i + 1, b = left ? i + 1 : i;    // (a, b, k) counter-clockwise
+            const int cur = new_tri(a, b, k);
+            if (prev_tri >= 0) {
+                // the previous and current triangle share the edge (i, k)
+                t[cur].n[slot_of_vertex(t[cur], i + 1)] = prev_tri;
+                t[prev_tri].n[slot_of_vertex(t[prev_tri], i - 1)] = cur;
+            }
+            prev_tri = cur;
+        }
+        // hull, counter-clockwise: left: 0,1,..,k-1,k ; right: k-1,..,1,0,k
+        std::vector<int> ring;
+        if (left) for (int i = 0; i < k; ++i) ring.push_back(i);
+        else for (int i = k - 1; i >= 0; --i) ring.push_back(i);
+        ring.push_back(k);
+        const int m = (int)ring.size();
+        for (int i = 0; i < m; ++i) { next_[ring[i]] = ring[(i + 1) % m]; prev_[ring[(i + 1) % m]] = ring[i]; }
+        for (int i = 0; i + 1 < k; ++i) hull_tri_[left ? i : i + 1] = i;          // run edges
+        hull_tri_[ring[m - 2]] = left ? k - 2 : 0;                                 // last run point -> k
+        hull_tri_[k] = left ? 0 : k - 2;                                           // k -> first ring point
+    }
+
+    bool sees(int u, int q) const { return orient(p[u], p[next_[u]], p[q]) < 0; }
+
+    // Joins point q (outside the hull) to all hull edges it sees; `hint` is a hull vertex next to one.
+    void add_outside(int q, int hint) {
+        int first = -1;                   // first vertex (in hull order) of the visible chain
+        if (sees(hint, q)) first = hint;
+        else if (sees(prev_[hint], q)) first = prev_[hint];
+        else {                            // not expected for sorted input; search the whole hull
+            int u = next_[hint];
+            while (u != hint && !sees(u, q)) u = next_[u];
+            if (!sees(u, q)) return;
+            first = u;
+        }
+        while (sees(prev_[first], q)) first = prev_[first];
+        int u = first, prev_tri = -1, first_tri = -1;
+        while (sees(u, q)) {
+            const int w = next_[u];
+            const int old = hull_tri_[u];
+            const int cur = new_tri(u, q, w);                        // counter-clockwise, see orient(u, w, q) < 0
+            t[cur].n[1] = old;                                       // across (w, u), opposite q
+            t[old].n[slot_of_hull_edge(old, u, w)] = cur;
+            if (prev_tri >= 0) {                                     // shares edge (u, q) with the previous fan triangle
+                t[cur].n[2] = prev_tri;                              // opposite w: edge (u, q)
+                t[prev_tri].n[0] = cur;                              // previous = (u', q, u): opposite u' is edge (q, u)
+            }
+            stack_.push_back(std::make_pair(cur, 1));
+            if (first_tri < 0) first_tri = cur;
+            prev_tri = cur;
+            u = w;
+        }
+        // hull: first -> q -> u; the fan's first triangle owns edge (first, q), its last owns (q, u)
+        const int last = u;
+        next_[first] = q; prev_[q] = first; next_[q] = last; prev_[last] = q;
+        hull_tri_[first] = first_tri;
+        hull_tri_[q] = prev_tri;
+        legalise();
+    }
+
+    // Slot of triangle x whose opposite edge is the hull edge u -> w.
+    int slot_of_hull_edge(int x, int u, int w) const {
+        for (int i = 0; i < 3; ++i)
+            if (t[x].v[(i + 1) % 3] == u && t[x].v[(i + 2) % 3] == w) return i;
+        return 0;
+    }
+
+    void note_hull_edges(int x) {
+        for (int i = 0; i < 3; ++i)
+            if (t[x].n[i] < 0) hull_tri_[t[x].v[(i + 1) % 3]] = x;
+    }
+
+    void legalise() {
+        while (!stack_.empty()) {
+            const int t1 = stack_.back().first, e1 = stack_.back().second;
+            stack_.pop_back();
+            const int t2 = t[t1].n[e1];
+            if (t2 < 0) continue;
+            const int e2 = slot_of_neighbour(t[t2], t1);
+            const int p1 = t[t1].v[e1], a = t[t1].v[(e1 + 1) % 3], b = t[t1].v[(e1 + 2) % 3], p2 = t[t2].v[e2];
+            if (in_circle(p[p1], p[a], p[b], p[p2]) <= 0) continue;
+            // quad p1, a, p2, b (counter-clockwise): replace diagonal (a, b) by (p1, p2)
+            const int n_p1a = t[t1].n[(e1 + 2) % 3], n_bp1 = t[t1].n[(e1 + 1) % 3];
+            const int n_p2b = t[t2].n[(e2 + 2) % 3], n_ap2 = t[t2].n[(e2 + 1) % 3];
+            Tri &x = t[t1], &y = t[t2];
+            x.v[0] = p1; x.v[1] = a; x.v[2] = p2; x.n[0] = n_ap2; x.n[1] = t2; x.n[2] = n_p1a;
+            y.v[0] = p1; y.v[1] = p2; y.v[2] = b; y.n[0] = n_p2b; y.n[1] = n_bp1; y.n[2] = t1;
+            if (n_ap2 >= 0) t[n_ap2].n[slot_of_neighbour(t[n_ap2], t2)] = t1;
+            if (n_bp1 >= 0) t[n_bp1].n[slot_of_neighbour(t[n_bp1], t1)] = t2;
+            note_hull_edges(t1);
+            note_hull_edges(t2);
+            stack_.push_back(std::make_pair(t1, 0));
+            stack_.push_back(std::make_pair(t1, 2));
+            stack_.push_back(std::make_pair(t2, 0));
+            stack_.push_back(std::make_pair(t2, 1));
+        }
+    }
+};
+
+struct TriOut { int v[3]; };
+
+// Triangulates; triangles come out as indices into the caller's point list (the first occurrence of
+// a repeated position), each rotated so that its smallest index leads, sorted lexicographically.
+int triangulate(const int32_t *xy, int n, std::vector<TriOut> &out) {
+    std::vector<Pt> pts(n);
+    for (int i = 0; i < n; ++i) {
+        pts[i].x = xy[2 * i]; pts[i].y = xy[2 * i + 1]; pts[i].id = i;
+        if (pts[i].x < -(1 << 23) || pts[i].x > (1 << 23) || pts[i].y < -(1 << 23) || pts[i].y > (1 << 23)) return -1;
+    }
+    std::sort(pts.begin(), pts.end(), [](const Pt &a, const Pt &b) { return a.x != b.x ? a.x < b.x : (a.y != b.y ? a.y < b.y : a.id < b.id); });
+    Delaunay d;
+    for (int i = 0; i < n; ++i)
+        if (d.p.empty() || d.p.back().x != pts[i].x || d.p.back().y != pts[i].y) d.p.push_back(pts[i]);
+    d.build();
+    out.resize(d.t.size());
+    for (size_t i = 0; i < d.t.size(); ++i) {
+        int v[3] = {d.p[d.t[i].v[0]].id, d.p[d.t[i].v[1]].id, d.p[d.t[i].v[2]].id};
+        const int lead = v[0] < v[1] ? (v[0] < v[2] ? 0 : 2) : (v[1] < v[2] ? 1 : 2);
+        for (int k = 0; k < 3; ++k) out[i].v[k] = v[(lead + k) % 3];
+    }
+    std::sort(out.begin(), out.end(), [](const TriOut &a, const TriOut &b) {
+        return a.v[0] != b.v[0] ? a.v[0] < b.v[0] : (a.v[1] != b.v[1] ? a.v[1] < b.v[1] : a.v[2] < b.v[2]);
+    });
+    return 0;
+}
+
+}  // namespace
+
+SVX_API int svx_delaunay(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, int32_t *tri_idx_host, int capacity, int *n_tri) {
+    // host-only: ctx may be null (then no message is recorded)
+    SVX_REQUIRE(ctx, n_pts >= 0 && capacity >= 0 && n_tri, SVX_ERR_INVALID_ARG, "svx_delaunay: bad count or null result");
+    SVX_REQUIRE(ctx, n_pts == 0 || pts_xy_host, SVX_ERR_INVALID_ARG, "svx_delaunay: null point list");
+    SVX_REQUIRE(ctx, capacity == 0 || tri_idx_host, SVX_ERR_INVALID_ARG, "svx_delaunay: null triangle buffer");
+    std::vector<TriOut> tris;
+    if (triangulate(pts_xy_host, n_pts, tris) != 0)
+        return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "svx_delaunay: coordinates must lie within +-2^23");
+    *n_tri = (int)tris.size();
+    const int m = std::min((int)tris.size(), capacity);
+    for (int i = 0; i < m; ++i)
+        for (int k = 0; k < 3; ++k) tri_idx_host[3 * i + k] = tris[i].v[k];
+    return SVX_OK;
+}
+
+// Triangulates the support points, fits the triangles' disparity planes and rasterises the plane prior.
+SVX_API int svx_mesh_plane_prior(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, const float *disparities, int rows, int cols,
+                                 float *prior, int *n_tri_out) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, n_pts >= 0, SVX_ERR_INVALID_ARG, "svx_mesh_plane_prior: negative point count");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_mesh_plane_prior: empty image");
+    SVX_REQUIRE(ctx, disparities && prior && (n_pts == 0 || pts_xy_host), SVX_ERR_INVALID_ARG, "svx_mesh_plane_prior: null pointer");
+    for (int i = 0; i < n_pts; ++i)
+        SVX_REQUIRE(ctx, pts_xy_host[2 * i] >= 0 && pts_xy_host[2 * i] < cols && pts_xy_host[2 * i + 1] >= 0 && pts_xy_host[2 * i + 1] < rows,
+                    SVX_ERR_INVALID_ARG, "svx_mesh_plane_prior: support point outside the image");
+    std::vector<TriOut> tris;
+    if (triangulate(pts_xy_host, n_pts, tris) != 0) return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "svx_mesh_plane_prior: coordinate range");
+    const int nt = (int)tris.size();
+    if (n_tri_out) *n_tri_out = nt;
+    if (nt == 0) return SVX_OK;
+    // device staging lives outside the workspace: the rasteriser reserves the workspace itself
+    void *pin;
+    rc = svx_pinned_reserve(ctx, (size_t)nt * 6 * sizeof(int32_t), &pin);
+    if (rc) return rc;
+    int32_t *h = (int32_t *)pin;
+    for (int i = 0; i < nt; ++i)
+        for (int k = 0; k < 3; ++k) {
+            h[6 * i + 2 * k] = pts_xy_host[2 * tris[i].v[k]];
+            h[6 * i + 2 * k + 1] = pts_xy_host[2 * tris[i].v[k] + 1];
+        }
+    void *dbuf = nullptr;
+    const size_t xy_bytes = (size_t)nt * 6 * sizeof(int32_t), abc_bytes = (size_t)nt * 3 * sizeof(float);
+    hipError_t e = hipMalloc(&dbuf, xy_bytes + abc_bytes);
+    if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_mesh_plane_prior: triangle buffer: %s", hipGetErrorString(e));
+    int32_t *d_xy = (int32_t *)dbuf;
+    float *d_abc = (float *)((char *)dbuf + xy_bytes);
+    rc = SVX_OK;
+    if (hipMemcpyAsync(d_xy, h, xy_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = svx_fail(ctx, SVX_ERR_HIP, "svx_mesh_plane_prior: upload failed");
+    if (!rc) rc = svx_plane_fit(ctx, d_xy, nt, disparities, rows, cols, d_abc);
+    if (!rc) rc = svx_plane_prior_raster(ctx, d_xy, d_abc, nt, rows, cols, prior);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dbuf);
+    return rc;
+}

@@ -58,6 +58,10 @@ lib.orc_alter_rows.argtypes = [_p] + [C.c_int] * 7
 lib.orc_sparse_nonmax.argtypes = [_p, _p, C.c_int, _p]
 lib.orc_arc9.restype = C.c_int
 lib.orc_arc9.argtypes = [C.c_uint]
+lib.orc_delaunay_check.restype = C.c_int
+lib.orc_delaunay_check.argtypes = [_p, C.c_int, _p, C.c_int]
+lib.orc_point_cloud.restype = C.c_int
+lib.orc_point_cloud.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_double, _p, _p]
 lib.orc_exfast_detect.restype = C.c_int
 lib.orc_exfast_detect.argtypes = [_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _p, _p, C.c_int]
 
@@ -251,6 +255,24 @@ def exfast_detect(img, min_threshold, adaptivity, nonmax=True, round_sat=False):
     resp = np.zeros(cap, np.float32)
     n = lib.orc_exfast_detect(_ptr(img), rows, cols, min_threshold, adaptivity, int(nonmax), int(round_sat), _ptr(xy), _ptr(resp), cap)
     return xy[:n].copy(), resp[:n].copy()
+
+
+def delaunay_check(pts_xy, tri):
+    pts = np.ascontiguousarray(pts_xy, dtype=np.int32).reshape(-1, 2)
+    tri = np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
+    return lib.orc_delaunay_check(_ptr(pts), len(pts), _ptr(tri) if len(tri) else None, len(tri))
+
+
+def point_cloud(pts_xy, disp, q, roi=(0, 0), bgr=None, max_range=8000.0):
+    pts = np.ascontiguousarray(pts_xy, dtype=np.int32).reshape(-1, 2)
+    disp = np.ascontiguousarray(disp, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(16)
+    xyz = np.zeros((max(len(pts), 1), 3), np.float64)
+    rgb = np.zeros((max(len(pts), 1), 3), np.uint8) if bgr is not None else None
+    n = lib.orc_point_cloud(_ptr(pts), len(pts), _ptr(disp), disp.shape[1], roi[0], roi[1], _ptr(q),
+                            _ptr(bgr) if bgr is not None else None, bgr.shape[1] if bgr is not None else 0, max_range,
+                            _ptr(xyz), _ptr(rgb) if rgb is not None else None)
+    return xyz[:n], (rgb[:n] if rgb is not None else None)
 
 
 # ---- the formula image of tests/golden/survey_kat.json ----

@@ -193,3 +193,65 @@ def test_detector_feeds_sparse_matcher(ctx):
     assert len(want[0]) > 10
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+# ------------------------------------------------------------------ support-point mesh
+@pytest.mark.parametrize("rows,cols,n", [(64, 96, 12), (375, 1242, 900), (368, 1232, 5000), (40, 40, 3)])
+def test_mesh_plane_prior(ctx, rows, cols, n):
+    """Triangulation + plane table + interpolation loop in one call against the oracle's plane fit and
+    rasteriser run over the same triangle list (the triangulation itself is checked in test_mesh_cpu.py)."""
+    import stereovision_amd as S
+    rng = np.random.default_rng(rows + n)
+    pts = np.unique(np.stack([rng.integers(0, cols, n), rng.integers(0, rows, n)], 1).astype(np.int32), axis=0)
+    pts = pts[rng.permutation(len(pts))]
+    disp = np.zeros((rows, cols), np.float32)
+    disp[pts[:, 1], pts[:, 0]] = rng.integers(0, 64, len(pts)).astype(np.float32)
+    tri = S.delaunay(pts)
+    assert O.delaunay_check(pts, tri) == 0
+    tri_xy = pts[tri].reshape(-1, 6)
+    abc = np.stack([O.plane_fit(np.concatenate([np.concatenate([pts[v], [disp[pts[v][1], pts[v][0]]]]) for v in t])) for t in tri]) \
+        if len(tri) else np.zeros((0, 3), np.float32)
+    want = O.plane_prior_raster(tri_xy, abc, rows, cols, disp.copy())
+    prior = dev(disp.copy())
+    got, nt = ctx.mesh_plane_prior(pts, dev(disp), prior)
+    assert nt == len(tri)
+    assert np.array_equal(got.cpu().numpy(), want)
+    # in place on the disparity map, as the reference's loop does (highPerfStereoLib.cpp:534-553): the
+    # vertex disparities are read by the plane fit before the rasteriser overwrites anything
+    d = dev(disp.copy())
+    ctx.mesh_plane_prior(pts, d, d)
+    assert np.array_equal(d.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------ point cloud
+Q_KITTI = np.array([[1, 0, 0, -609.5593], [0, 1, 0, -172.854], [0, 0, 0, 721.5377], [0, 0, 1.0 / 0.54, 0]], np.float64)
+
+
+@pytest.mark.parametrize("rows,cols,n", [(375, 1242, 100000), (64, 80, 1), (64, 80, 1023), (64, 80, 1025), (64, 80, 5000)])
+def test_point_cloud(ctx, rows, cols, n):
+    rng = np.random.default_rng(rows + n)
+    roi = (7, 3)
+    pts = np.stack([rng.integers(0, cols, n), rng.integers(0, rows, n)], 1).astype(np.int32)
+    disp = rng.integers(-2, 90, size=(rows, cols)).astype(np.float32) * 0.25
+    bgr = rng.integers(0, 256, size=(rows + 9, cols + 11, 3), dtype=np.uint8)
+    for q, max_range in ((Q_KITTI, 8000.0), (Q_KITTI * 1000.0, 8000.0), (rng.normal(size=(4, 4)), 3.0)):
+        wxyz, wrgb = O.point_cloud(pts, disp, q, roi, bgr, max_range)
+        xyz, rgb, k = ctx.point_cloud(dev(pts), dev(disp), q, roi, dev(bgr), max_range)
+        assert k == len(wxyz)
+        # double precision, same expression order on both sides, no contraction: bit-exact
+        assert np.array_equal(xyz.cpu().numpy(), wxyz)
+        assert np.array_equal(rgb.cpu().numpy(), wrgb)
+    wxyz, _ = O.point_cloud(pts, disp, Q_KITTI, (0, 0), None)
+    xyz, rgb, k = ctx.point_cloud(dev(pts), dev(disp), Q_KITTI, capacity=min(10, n))
+    assert rgb is None and k == len(wxyz) and np.array_equal(xyz.cpu().numpy(), wxyz[:min(10, n)])
+
+
+def test_point_cloud_rejects_points_outside(ctx):
+    import stereovision_amd as S
+    disp = dev(np.zeros((20, 30), np.float32))
+    with pytest.raises(S.SvxError):
+        ctx.point_cloud(dev(np.array([[30, 0]], np.int32)), disp, Q_KITTI)
+    with pytest.raises(S.SvxError):
+        ctx.point_cloud(dev(np.array([[5, 5]], np.int32)), disp, Q_KITTI, roi=(28, 0), bgr=dev(np.zeros((20, 30, 3), np.uint8)))
+    xyz, rgb, k = ctx.point_cloud(dev(np.zeros((0, 2), np.int32)), disp, Q_KITTI)
+    assert k == 0

@@ -1,0 +1,92 @@
+"""Host-side Delaunay triangulation of libsvx (no GPU needed): checked against the definition by
+the oracle's brute-force checker, and against scipy's Qhull triangulation where the triangulation
+is unique (no four cocircular points)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import stereovision_amd as S
+
+
+def canon(tri):
+    """Orientation-free canonical form: sorted vertex triples, sorted list."""
+    return sorted(tuple(sorted(map(int, t))) for t in tri)
+
+
+def random_points(rng, n, w, h):
+    return np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("n,w,h", [(3, 10, 10), (4, 50, 50), (10, 100, 100), (60, 1242, 375), (300, 1242, 375), (1200, 1242, 375), (400, 40, 30)])
+def test_delaunay_satisfies_definition(n, w, h):
+    rng = np.random.default_rng(n * 7 + w)
+    for trial in range(3):
+        pts = random_points(rng, n, w, h)
+        tri = S.delaunay(pts)
+        assert O.delaunay_check(pts, tri) == 0
+
+
+def test_delaunay_degenerate_inputs():
+    assert len(S.delaunay(np.zeros((0, 2), np.int32))) == 0
+    assert len(S.delaunay([[1, 1]])) == 0
+    assert len(S.delaunay([[1, 1], [5, 9]])) == 0
+    assert len(S.delaunay([[0, 0], [1, 1], [2, 2], [7, 7]])) == 0              # collinear
+    assert len(S.delaunay([[3, 3]] * 5)) == 0                                   # one position
+    # vertical and horizontal leading runs, both sides
+    for pts in ([[0, 0], [0, 1], [0, 2], [0, 3], [2, 1]], [[0, 0], [0, 1], [0, 2], [2, -5]], [[0, 0], [1, 0], [2, 0], [3, 0], [3, 4]],
+                [[0, 5], [0, 6], [1, 0]], [[0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [1, 2], [2, 0], [2, 1], [2, 2]]):
+        pts = np.array(pts, np.int32)
+        tri = S.delaunay(pts)
+        assert len(tri) > 0 and O.delaunay_check(pts, tri) == 0, pts.tolist()
+    # full integer lattice (every quad cocircular) and repeated positions
+    y, x = np.mgrid[0:12, 0:17]
+    grid = np.stack([x.ravel(), y.ravel()], 1).astype(np.int32)
+    tri = S.delaunay(grid)
+    assert len(tri) == 2 * 11 * 16 and O.delaunay_check(grid, tri) == 0
+    rng = np.random.default_rng(0)
+    dup = np.concatenate([grid[rng.permutation(len(grid))], grid[:40]])
+    tri = S.delaunay(dup)
+    assert O.delaunay_check(dup, tri) == 0
+    assert tri.max() < len(grid)                                               # first occurrence represents a position
+
+
+def test_delaunay_output_is_canonical():
+    rng = np.random.default_rng(5)
+    pts = random_points(rng, 200, 300, 200)
+    tri = S.delaunay(pts)
+    assert np.all(tri[:, 0] < tri[:, 1]) and np.all(tri[:, 0] < tri[:, 2])
+    keys = [tuple(t) for t in tri.tolist()]
+    assert keys == sorted(keys)
+    # same orientation for all triangles
+    a, b, c = pts[tri[:, 0]].astype(np.int64), pts[tri[:, 1]].astype(np.int64), pts[tri[:, 2]].astype(np.int64)
+    o = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+    assert np.all(o > 0)
+
+
+def test_delaunay_matches_qhull_in_general_position():
+    scipy_spatial = pytest.importorskip("scipy.spatial")
+    rng = np.random.default_rng(11)
+    for n in (20, 150, 800):
+        # a large coordinate range makes cocircular quadruples and collinear hull triples very unlikely;
+        # the checker would also flag a non-Delaunay result independently
+        pts = np.unique(random_points(rng, n, 1 << 20, 1 << 20), axis=0)
+        tri = S.delaunay(pts)
+        assert O.delaunay_check(pts, tri) == 0
+        ref = scipy_spatial.Delaunay(pts.astype(np.float64)).simplices
+        assert canon(tri) == canon(ref)
+
+
+def test_checker_rejects_wrong_meshes():
+    pts = np.array([[0, 0], [10, 0], [10, 10], [0, 10], [3, 4]], np.int32)
+    good = S.delaunay(pts)
+    assert O.delaunay_check(pts, good) == 0
+    assert O.delaunay_check(pts, good[:-1]) != 0                                # hole
+    assert O.delaunay_check(pts, np.array([[0, 1, 2], [0, 2, 3]], np.int32)) != 0   # point 4 unused
+    quad = np.array([[0, 0], [10, 0], [11, 5], [0, 4]], np.int32)
+    a = np.array([[0, 1, 2], [0, 2, 3]], np.int32); b = np.array([[0, 1, 3], [1, 2, 3]], np.int32)
+    assert sorted([O.delaunay_check(quad, a) == 0, O.delaunay_check(quad, b) == 0]) == [False, True]
+
+
+def test_delaunay_rejects_out_of_range():
+    with pytest.raises(S.SvxError):
+        S.delaunay([[0, 0], [1 << 25, 3], [5, 5]])
