@@ -191,6 +191,32 @@ int svx_plane_fit(svx_ctx *ctx, const int32_t *tri_xy, int n_tri, const float *d
 int svx_plane_prior_raster(svx_ctx *ctx, const int32_t *tri_xy, const float *tri_abc, int n_tri,
                            int rows, int cols, float *prior);
 
+/* ---- 64-bit descriptors, right view, left-right check (no counterpart in the reference) ----
+ * Generalisations of svx_dense_wta5x5 for the 9x7 / 128-disparity configuration; the reference
+ * has 5x5 (sparsestereo/census.cpp) and a square NxN census (denseCensusStereo/
+ * CensusTransform.cpp:33-67) only, and a dense consistency check only in libelas
+ * (elas/elas.cpp:909-979), which these follow in spirit.
+ * svx_census9x7_u8: descriptor of pixel (x,y), 4 <= x < cols-4, 3 <= y < rows-3: neighbour
+ *   (dy,dx), dy=-3..3, dx=-4..4, index (dy+3)*9+(dx+4), bit 62-index, set when centre >
+ *   neighbour; census[2p] = bits 0..31, census[2p+1] = bits 32..62; other pixels 0.
+ * svx_dense_wta: svx_dense_wta5x5's search (5x5 aggregation, x_r >= 5, strict '<') on
+ *   descriptors of `words` 32-bit words (1 or 2, interleaved per pixel), the whole map written
+ *   (border 0).  SVX_VIEW_RIGHT gives the right image's map: for (x_r, y) scan
+ *   x_l = x_r, x_r+1, ... while x_l <= cols-6 and x_l < x_r + max_disp, disparity = x_l - x_r
+ *   of the first minimum.
+ * svx_lr_check: for 2 <= x < cols-2, 2 <= y < rows-2: d = disp_left(y,x), x_r = x - (int)d;
+ *   disp_left(y,x) = invalid_value when x_r < 2 or |disp_right(y,x_r) - d| > threshold.
+ * svx_dense_census9x7_lr_u8: census of both images, left-view search, and for
+ *   lr_threshold >= 0 the right-view search and the check (invalid = -1). */
+enum svx_view { SVX_VIEW_LEFT = 0, SVX_VIEW_RIGHT = 1 };
+int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census, int rows, int cols, int n_frames);
+int svx_dense_wta(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
+                  int words, int max_disp, int view, float *disparity);
+int svx_lr_check(svx_ctx *ctx, float *disp_left, const float *disp_right, int rows, int cols, int n_frames,
+                 float threshold, float invalid_value);
+int svx_dense_census9x7_lr_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
+                              int max_disp, float lr_threshold, float *disparity);
+
 /* ---- steps either side of the census path ----------------------------------
  * Pre-processing of highPerfStereo(), highPerfStereoLib.cpp:245-335.  Its
  * arithmetic is OpenCV's (not part of the reference tree); the entry points

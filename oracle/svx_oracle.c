@@ -919,3 +919,66 @@ ORC_API int orc_point_cloud(const int32_t *pts_xy, int n, const float *disp, int
     }
     return out;
 }
+
+/* ------------------------------------------------------- 64-bit descriptors --
+ * Build-defined generalisations for the 9x7 / left-right-check configuration.  The reference has
+ * no 9x7 census and no dense left-right check (its generic census is square,
+ * denseCensusStereo/CensusTransform.cpp:33-67; the only dense consistency check is libelas',
+ * elas/elas.cpp:909-979): nothing to pin on, these functions ARE the definition.
+ *
+ * orc_census9x7: pixel (x,y), 4 <= x < cols-4, 3 <= y < rows-3: neighbour (dy,dx), dy=-3..3,
+ * dx=-4..4, index (dy+3)*9+(dx+4), bit 62-index set when centre > neighbour; out[2p] = bits 0..31,
+ * out[2p+1] = bits 32..62; every other pixel 0. */
+ORC_API void orc_census9x7(const uint8_t *img, int rows, int cols, uint32_t *out) {
+    memset(out, 0, sizeof(uint32_t) * 2 * (size_t)rows * cols);
+    for (int y = 3; y < rows - 3; ++y)
+        for (int x = 4; x < cols - 4; ++x) {
+            uint64_t w = 0;
+            const int c = img[(long)y * cols + x];
+            for (int dy = -3; dy <= 3; ++dy)
+                for (int dx = -4; dx <= 4; ++dx) {
+                    if (!dy && !dx) continue;
+                    if (c > (int)img[(long)(y + dy) * cols + x + dx]) w |= 1ull << (62 - ((dy + 3) * 9 + (dx + 4)));
+                }
+            out[2 * ((long)y * cols + x)] = (uint32_t)w;
+            out[2 * ((long)y * cols + x) + 1] = (uint32_t)(w >> 32);
+        }
+}
+
+/* The search of orc_dense_wta5x5 (denseCensusStereo.cpp:87-131) on descriptors of `words` words,
+ * whole map written (border 0), rows y0 <= y < y1 only (for timing a bounded sample).
+ * view 0: left image's map.  view 1: right image's map: for (xr,y) scan xl = xr, xr+1, ... while
+ * xl <= cols-6 and xl < xr+maxDisp; first minimum wins; disparity = xl - xr. */
+ORC_API void orc_dense_wta_words(const uint32_t *cl, const uint32_t *cr, int rows, int cols, int words, int maxDisp, int view,
+                                 float *disp, int y0, int y1) {
+    for (int y = y0 < 0 ? 0 : y0; y < (y1 > rows ? rows : y1); ++y)
+        for (int x = 0; x < cols; ++x) {
+            float d = 0.f;
+            if (y >= 2 && y < rows - 2 && x >= 2 && x < cols - 2) {
+                int minCost = INT_MAX, best = x;
+                for (int k = 0; k < maxDisp; ++k) {
+                    const int xl = view ? x + k : x, xr = view ? x : x - k;
+                    if (view ? xl > cols - 6 : xr < 5) break;
+                    int cost = 0;
+                    for (int m = -2; m <= 2; ++m)
+                        for (int n = -2; n <= 2; ++n)
+                            for (int w = 0; w < words; ++w)
+                                cost += __builtin_popcount(cl[((long)(y + m) * cols + xl + n) * words + w] ^ cr[((long)(y + m) * cols + xr + n) * words + w]);
+                    if (cost < minCost) { minCost = cost; best = k; }
+                }
+                d = minCost == INT_MAX ? 0.f : (float)best;
+            }
+            disp[(long)y * cols + x] = d;
+        }
+}
+
+/* Left-right check: 2 <= x < cols-2, 2 <= y < rows-2: d = dl(y,x), xr = x - (int)d; dl(y,x) = invalid when
+ * xr < 2 or |dr(y,xr) - d| > threshold. */
+ORC_API void orc_lr_check(float *dl, const float *dr, int rows, int cols, float threshold, float invalid) {
+    for (int y = 2; y < rows - 2; ++y)
+        for (int x = 2; x < cols - 2; ++x) {
+            const float d = dl[(long)y * cols + x];
+            const int xr = x - (int)d;
+            if (xr < 2 || fabsf(dr[(long)y * cols + xr] - d) > threshold) dl[(long)y * cols + x] = invalid;
+        }
+}

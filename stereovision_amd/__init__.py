@@ -17,6 +17,8 @@ from ._lib import (  # noqa: F401
     WINDOW_5X5,
     EXFAST_NONMAX,
     EXFAST_THRESHOLD_ROUND_SAT,
+    VIEW_LEFT,
+    VIEW_RIGHT,
     EXPORTS,
     DOMINANT_KERNEL,
     dominant_kernel_timer,
@@ -24,4 +26,4 @@ from ._lib import (  # noqa: F401
 )
 
 __all__ = ["Context", "SvxError", "lib_path", "load_library", "CENSUS_SSE24", "CENSUS_GENERIC25",
-           "CENSUS_ZERO_REST", "WINDOW_5X6", "WINDOW_5X5", "EXFAST_NONMAX", "EXFAST_THRESHOLD_ROUND_SAT", "EXPORTS"]
+           "CENSUS_ZERO_REST", "WINDOW_5X6", "WINDOW_5X5", "EXFAST_NONMAX", "EXFAST_THRESHOLD_ROUND_SAT", "VIEW_LEFT", "VIEW_RIGHT", "EXPORTS"]

@@ -7,6 +7,7 @@ import numpy as np
 
 CENSUS_SSE24, CENSUS_GENERIC25, CENSUS_ZERO_REST = 0, 1, 16
 EXFAST_NONMAX, EXFAST_THRESHOLD_ROUND_SAT = 1, 2
+VIEW_LEFT, VIEW_RIGHT = 0, 1
 WINDOW_5X6, WINDOW_5X5 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,6 +45,10 @@ EXPORTS = {
     "svx_refine": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, C.c_uint, _vp, _vp] + [_vp] * 7),
     "svx_plane_fit": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
     "svx_plane_prior_raster": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "svx_census9x7_u8": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "svx_dense_wta": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "svx_lr_check": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float]),
+    "svx_dense_census9x7_lr_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_float, _vp]),
     "svx_crop16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "svx_equalize_hist": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "svx_laplacian_abs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_double, C.c_double]),
@@ -261,6 +266,50 @@ class Context:
             out = t.empty(left.shape, dtype=t.float32, device=left.device)
         _check_dev(out, t.float32, "out")
         self._call("svx_dense_census_wta_u8", _dptr(left), _dptr(right), r, c, f, int(max_disp), _dptr(out))
+        return out
+
+    # ---- 64-bit descriptors, right view, left-right check ----
+    def census9x7(self, img):
+        """[.., rows, cols] uint8 -> [.., rows, cols, 2] int32 (two words per descriptor)."""
+        t = self._torch
+        _check_dev(img, t.uint8, "img")
+        f, r, c = _frames(img)
+        out = t.empty(tuple(img.shape) + (2,), dtype=t.int32, device=img.device)
+        self._call("svx_census9x7_u8", _dptr(img), _dptr(out), r, c, f)
+        return out
+
+    def dense_wta(self, census_left, census_right, max_disp, view=VIEW_LEFT, words=1, out=None):
+        """census tensors: [.., rows, cols] (words=1) or [.., rows, cols, 2] (words=2) int32."""
+        t = self._torch
+        _check_dev(census_left, t.int32, "census_left"); _check_dev(census_right, t.int32, "census_right")
+        if census_left.shape != census_right.shape:
+            raise SvxError(-2, "Mismatching image sizes")
+        img_shape = census_left.shape[:-1] if words == 2 else census_left.shape
+        f, r, c = (1,) + tuple(img_shape) if len(img_shape) == 2 else tuple(img_shape)
+        if out is None:
+            out = t.empty(tuple(img_shape), dtype=t.float32, device=census_left.device)
+        _check_dev(out, t.float32, "out")
+        self._call("svx_dense_wta", _dptr(census_left), _dptr(census_right), r, c, f, int(words), int(max_disp), int(view), _dptr(out))
+        return out
+
+    def lr_check(self, disp_left, disp_right, threshold, invalid=-1.0):
+        """In place on disp_left."""
+        t = self._torch
+        _check_dev(disp_left, t.float32, "disp_left"); _check_dev(disp_right, t.float32, "disp_right")
+        f, r, c = _frames(disp_left)
+        self._call("svx_lr_check", _dptr(disp_left), _dptr(disp_right), r, c, f, float(threshold), float(invalid))
+        return disp_left
+
+    def dense_census9x7_lr(self, left, right, max_disp, lr_threshold=1.0, out=None):
+        t = self._torch
+        _check_dev(left, t.uint8, "left"); _check_dev(right, t.uint8, "right")
+        if left.shape != right.shape:
+            raise SvxError(-2, "Mismatching image sizes")
+        f, r, c = _frames(left)
+        if out is None:
+            out = t.empty(left.shape, dtype=t.float32, device=left.device)
+        _check_dev(out, t.float32, "out")
+        self._call("svx_dense_census9x7_lr_u8", _dptr(left), _dptr(right), r, c, f, int(max_disp), float(lr_threshold), _dptr(out))
         return out
 
     # ---- a9 ----

@@ -18,35 +18,36 @@
 #include <cstdlib>
 
 // ---------------------------------------------------------------------------
+template <int WORDS>
 __global__ __launch_bounds__(256) void dense_wta5x5_plain_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                                  int rows, int cols, int max_disp, float *__restrict__ disp_all,
-                                                                 int write_border) {
+                                                                 int write_border, int mirror) {
     const long n = (long)rows * cols;
-    const uint32_t *cl = cl_all + (long)blockIdx.z * n;
-    const uint32_t *cr = cr_all + (long)blockIdx.z * n;
+    const uint32_t *cl = cl_all + (long)blockIdx.z * n * WORDS;
+    const uint32_t *cr = cr_all + (long)blockIdx.z * n * WORDS;
     float *disp = disp_all + (long)blockIdx.z * n;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
+    // logical column c lives at memory column cols-1-c in mirrored mode
+    auto at = [&](int yy, int c) -> long { return (long)yy * cols + (mirror ? cols - 1 - c : c); };
     if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) {
-        if (write_border) disp[(long)y * cols + x] = 0.0f;
+        if (write_border) disp[at(y, x)] = 0.0f;
         return;
     }
-    uint32_t l[25];
-#pragma unroll
-    for (int m = 0; m < 5; ++m)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) l[m * 5 + k] = cl[(long)(y + m - 2) * cols + (x + k - 2)];
     int best = 0x7fffffff, bestx = x;
     for (int i = x; i >= 5 && i > x - max_disp; --i) {
         int cost = 0;
 #pragma unroll
         for (int m = 0; m < 5; ++m)
 #pragma unroll
-            for (int k = 0; k < 5; ++k) cost += popc32(l[m * 5 + k] ^ cr[(long)(y + m - 2) * cols + (i + k - 2)]);
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w)
+                    cost += popc32(cl[at(y + m - 2, x + k - 2) * WORDS + w] ^ cr[at(y + m - 2, i + k - 2) * WORDS + w]);
         if (cost < best) { best = cost; bestx = i; }
     }
-    disp[(long)y * cols + x] = (float)(x - bestx);
+    disp[at(y, x)] = (float)(x - bestx);
 }
 
 // ---------------------------------------------------------------------------
@@ -124,12 +125,18 @@ __device__ __forceinline__ uint32_t reduce16(const uint32_t (&k)[SW_T], int lane
 // One census row of the sweep, phase 1: fold the row into the running column sums.
 // cl: the 20 left words of the row (wavefront-uniform, in SGPRs); rp: this lane's view of the staged right
 // words, skewed by its disparity (lane l reads column xq + 63 - l + j).
-__device__ __forceinline__ void sweep_row_accumulate(SweepState &st, const uint32_t (&cl)[SW_C], const uint32_t *__restrict__ rp) {
-    uint32_t cr[SW_C];
+// WORDS = 32-bit words per census descriptor; word w of the staged row sits SW_SLOT_WORDS further on.
+template <int WORDS>
+__device__ __forceinline__ void sweep_row_accumulate(SweepState &st, const uint32_t (&cl)[SW_C * WORDS], const uint32_t *__restrict__ rp) {
+    uint32_t cr[WORDS][SW_C];
 #pragma unroll
-    for (int j = 0; j < SW_C; ++j) cr[j] = rp[j];
+    for (int w = 0; w < WORDS; ++w)
 #pragma unroll
-    for (int j = 0; j < SW_C; ++j) st.C[j] += (uint32_t)__builtin_popcount(cl[j] ^ cr[j]);
+        for (int j = 0; j < SW_C; ++j) cr[w][j] = rp[w * SW_SLOT_WORDS + j];
+#pragma unroll
+    for (int j = 0; j < SW_C; ++j)
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) st.C[j] += (uint32_t)__builtin_popcount(cl[j * WORDS + w] ^ cr[w][j]);
 }
 
 // Phase 2: form the 16 window keys and reduce them over the lanes.
@@ -168,10 +175,12 @@ __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, u
 // Sweeps one 64-disparity chunk of one (strip, 16-column block) and merges its winners into `best`.
 // xb is the first output column; census columns xb-2 .. xb+17 are all inside the row (the caller
 // guarantees 2 <= xb <= cols-18).
-template <bool MASKED>
+// MIRROR: logical column c lives at memory column cols-1-c (the right-view search is the left-view search on
+// the mirrored pair with the images swapped).
+template <bool MASKED, int WORDS, bool MIRROR>
 __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int cols, int max_disp,
                                             int xb, int y_lo, int n_rows, int chunk, int lane,
-                                            uint32_t (*stage)[SW_SLOT_WORDS], uint32_t (*best)[SW_T]) {
+                                            uint32_t (*stage)[WORDS * SW_SLOT_WORDS], uint32_t (*best)[SW_T]) {
     const int dbase = chunk << 6;
     const uint32_t d = (uint32_t)(dbase + lane);
     const uint32_t d_odd = (uint32_t)SW_DMASK - d;
@@ -189,39 +198,54 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
     // Right words: per row every lane fetches right column xq+l (g0) and, for l < 19, xq+64+l (g1).
     // Column indices are clamped into the row: a clamped word only ever feeds an inadmissible
     // (column, disparity) pair, which is masked out.
-    const unsigned c0 = (unsigned)min(max(xq + lane, 0), cols - 1);
-    const unsigned c1 = (unsigned)min(max(xq + 64 + (lane & 31), 0), cols - 1);
-    auto fetch = [&](int r, uint32_t &g0, uint32_t &g1) {
-        const uint32_t *rowp = cr + (long)(y_lo - 2 + r) * cols;   // uniform row base + per-lane column
-        g0 = rowp[c0];
-        g1 = rowp[c1];
+    const int lc0 = min(max(xq + lane, 0), cols - 1), lc1 = min(max(xq + 64 + (lane & 31), 0), cols - 1);
+    const unsigned c0 = (unsigned)(MIRROR ? cols - 1 - lc0 : lc0) * WORDS;
+    const unsigned c1 = (unsigned)(MIRROR ? cols - 1 - lc1 : lc1) * WORDS;
+    struct Fetched { uint32_t a[WORDS], b[WORDS]; };
+    auto fetch = [&](int r, Fetched &g) {
+        const uint32_t *rowp = cr + (long)(y_lo - 2 + r) * cols * WORDS;   // uniform row base + per-lane column
+        if (WORDS == 1) {
+            g.a[0] = rowp[c0];
+            g.b[0] = rowp[c1];
+        } else {
+            const uint2 va = *reinterpret_cast<const uint2 *>(rowp + c0), vb = *reinterpret_cast<const uint2 *>(rowp + c1);
+            g.a[0] = va.x; g.a[WORDS - 1] = va.y;
+            g.b[0] = vb.x; g.b[WORDS - 1] = vb.y;
+        }
     };
     uint32_t *const st_w0 = &stage[0][lane], *const st_w1 = &stage[0][64 + (lane & 31)];
     const uint32_t *const st_r = &stage[0][63 - lane];
-    auto stash = [&](int slot, uint32_t g0, uint32_t g1) {
-        st_w0[slot * SW_SLOT_WORDS] = g0;
-        st_w1[slot * SW_SLOT_WORDS] = g1;            // lanes l and l+32 store the same word
+    constexpr int SLOT_STRIDE = WORDS * SW_SLOT_WORDS;
+    auto stash = [&](int slot, const Fetched &g) {
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) {
+            st_w0[slot * SLOT_STRIDE + w * SW_SLOT_WORDS] = g.a[w];
+            st_w1[slot * SLOT_STRIDE + w * SW_SLOT_WORDS] = g.b[w];     // lanes l and l+32 store the same word
+        }
         __builtin_amdgcn_wave_barrier();            // the rows are read back by other lanes of this wavefront
     };
-    // Left words: 20 consecutive words of the row, the same for every lane -> scalar loads into SGPRs.
-    const uint32_t *lbase = cl + (xb - 2);
-    auto fetch_left = [&](int r, uint32_t (&w)[SW_C]) {
-        const uint32_t *lp = lbase + (long)(y_lo - 2 + r) * cols;
+    // Left words: 20 consecutive descriptors of the row, the same for every lane -> scalar loads into SGPRs.
+    // Mirrored, logical columns xb-2 .. xb+17 are memory columns cols-1-(xb-2) down to cols-1-(xb+17).
+    const uint32_t *lbase = cl + (long)(MIRROR ? cols - 1 - (xb + SW_T + 1) : xb - 2) * WORDS;
+    auto fetch_left = [&](int r, uint32_t (&w)[SW_C * WORDS]) {
+        const uint32_t *lp = lbase + (long)(y_lo - 2 + r) * cols * WORDS;
 #pragma unroll
-        for (int j = 0; j < SW_C; ++j) w[j] = lp[j];
+        for (int j = 0; j < SW_C; ++j)
+#pragma unroll
+            for (int k = 0; k < WORDS; ++k) w[j * WORDS + k] = lp[(MIRROR ? SW_C - 1 - j : j) * WORDS + k];
     };
 
     // Software pipeline over rows: the global fetch of row r+3 and the scalar fetch of row r+1 are in
     // flight while row r is processed.  Rows run in unconditional groups of ten (ring slot and sign are
     // compile-time); rows past the end of the strip re-read the last census row and their winners are dropped.
     const int last = n_rows - 1;
-    uint32_t g0, g1;
-    fetch(0, g0, g1);
-    stash(0, g0, g1);
-    fetch(min(1, last), g0, g1);
-    stash(1, g0, g1);
-    fetch(min(2, last), g0, g1);
-    uint32_t lw[SW_C];
+    Fetched g;
+    fetch(0, g);
+    stash(0, g);
+    fetch(min(1, last), g);
+    stash(1, g);
+    fetch(min(2, last), g);
+    uint32_t lw[SW_C * WORDS];
     fetch_left(0, lw);
 
     // The scalar fetch of the next row's left words is issued right after the current row's words were
@@ -230,10 +254,10 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
 #define SVX_ROW(RR)                                                                                   \
     {                                                                                                 \
         const int r = r0 + RR;                                                                        \
-        sweep_row_accumulate(st, lw, st_r + (RR % SW_SLOTS) * SW_SLOT_WORDS);                         \
+        sweep_row_accumulate<WORDS>(st, lw, st_r + (RR % SW_SLOTS) * SLOT_STRIDE);                    \
         fetch_left(min(r + 1, last), lw);                                                             \
-        stash((RR + 2) % SW_SLOTS, g0, g1);                                                           \
-        fetch(min(r + 3, last), g0, g1);                                                              \
+        stash((RR + 2) % SW_SLOTS, g);                                                                \
+        fetch(min(r + 3, last), g);                                                                   \
         const uint32_t zk = sweep_row_reduce<RR, MASKED>(st, lane, (RR & 1) ? d_odd : d, xlim_base, dmax); \
         if (r >= 4 && r < n_rows)                  /* output row y_lo + r - 4 */                      \
             atomicMin(&best[r - 4][lane & 15], zk);                                                   \
@@ -251,18 +275,18 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
 // x-block b covers output columns [xb, xb+16), xb = min(2 + 16 b, cols - 18): the last block is shifted
 // left so that it ends at column cols-3; the columns it shares with its neighbour get the same values
 // from both.  Requires cols >= 20.
-template <int WAVES_PER_SIMD>
+template <int WAVES_PER_SIMD, int WORDS, bool MIRROR>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                                  int rows, int cols, int max_disp, int strip_rows, int n_xblocks,
                                                                  float *__restrict__ disp_all, int write_border) {
-    __shared__ uint32_t lds_stage[4][SW_SLOTS][SW_SLOT_WORDS];
+    __shared__ uint32_t lds_stage[4][SW_SLOTS][WORDS * SW_SLOT_WORDS];
     __shared__ uint32_t lds_best[2][SW_MAX_STRIP][SW_T];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave >> 1, parity = wave & 1;
     const long n = (long)rows * cols;
-    const uint32_t *cl = cl_all + (long)blockIdx.z * n;
-    const uint32_t *cr = cr_all + (long)blockIdx.z * n;
+    const uint32_t *cl = cl_all + (long)blockIdx.z * n * WORDS;
+    const uint32_t *cr = cr_all + (long)blockIdx.z * n * WORDS;
     float *disp = disp_all + (long)blockIdx.z * n;
     const int xblock = blockIdx.x * 2 + pair;
     const bool active = xblock < n_xblocks;
@@ -271,7 +295,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
     // frame border the first strip also owns rows 0,1 and the last one rows rows-2, rows-1
     const int y_lo = 2 + blockIdx.y * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
     const int ys = blockIdx.y == 0 ? 0 : y_lo, y_end = blockIdx.y == gridDim.y - 1 ? rows : y_hi;
-    uint32_t (*stage)[SW_SLOT_WORDS] = lds_stage[wave];
+    uint32_t (*stage)[WORDS * SW_SLOT_WORDS] = lds_stage[wave];
     uint32_t (*best)[SW_T] = lds_best[pair];
     const int n_out = y_hi - y_lo;                          // >= 1 by construction of the grid
     const int half = parity * 64 + lane;                    // 0..127 over the two wavefronts of the pair
@@ -287,24 +311,25 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
             if (chunk > 0 && dbase > xb + SW_T - 1 - 5) break;
             // masking is needed when some (column, lane) pair is inadmissible
             const bool masked = (dbase + 63 > xb - 5) || (dbase + 63 > max_disp - 1);
-            if (masked) sweep_chunk<true>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
-            else sweep_chunk<false>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
+            if (masked) sweep_chunk<true, WORDS, MIRROR>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
+            else sweep_chunk<false, WORDS, MIRROR>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
         }
     }
     __syncthreads();
     if (!active) return;
     // write-out: 8 rows x 16 columns per pass over the pair
+    const int xo = MIRROR ? cols - 1 - (xb + (lane & 15)) : xb + (lane & 15);
     for (int o = (half >> 4); o < n_out; o += 8)
-        disp[(long)(y_lo + o) * cols + xb + (lane & 15)] = (float)(best[o][lane & 15] & SW_DMASK);
+        disp[(long)(y_lo + o) * cols + xo] = (float)(best[o][lane & 15] & SW_DMASK);
     if (write_border) {
         // the frame border is 0: rows outside [2, rows-2) over this block's columns, and the two
-        // border columns on either side (written by the first and the last block)
+        // border columns on either side (written by the first and the last block; the set is its own mirror image)
         for (int y = ys + (half >> 4); y < y_end; y += 8)
-            if (y < 2 || y >= rows - 2) disp[(long)y * cols + xb + (lane & 15)] = 0.0f;
-        if (xblock == 0 || xblock == n_xblocks - 1) {
-            const int xc = (xblock == 0 ? 0 : cols - 2) + (lane & 1);
-            for (int y = ys + (half >> 1); y < y_end; y += 64) disp[(long)y * cols + xc] = 0.0f;
-        }
+            if (y < 2 || y >= rows - 2) disp[(long)y * cols + xo] = 0.0f;
+        if (xblock == 0)
+            for (int y = ys + (half >> 1); y < y_end; y += 64) disp[(long)y * cols + (lane & 1)] = 0.0f;
+        if (xblock == n_xblocks - 1)
+            for (int y = ys + (half >> 1); y < y_end; y += 64) disp[(long)y * cols + cols - 2 + (lane & 1)] = 0.0f;
     }
 }
 
@@ -316,14 +341,9 @@ static int dense_args_ok(svx_ctx *ctx, const void *a, const void *b, const void 
     return SVX_OK;
 }
 
-static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
+template <int WORDS, bool MIRROR>
+static int launch_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
                         float *disparity, int write_border) {
-    if (max_disp > SW_DMASK + 1 || cols < SW_T + 4 || rows < 5) {
-        dim3 grid(svx_cdiv(cols, 64), svx_cdiv(rows, 4), n_frames);
-        dense_wta5x5_plain_kernel<<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity, write_border);
-        SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_plain_kernel");
-        return SVX_OK;
-    }
     // strips of SW_MAX_STRIP output rows from row 2 on: strip + 4 halo rows is a whole number of 10-row groups
     const int strip_rows = SW_MAX_STRIP;
     const int n_strips = (rows - 4 + strip_rows - 1) / strip_rows;
@@ -332,11 +352,27 @@ static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     // Tuning knob: SVX_SWEEP_OCC=2 selects the build that may use up to 256 VGPRs (2 wavefronts per SIMD).
     static const int occ = [] { const char *e = getenv("SVX_SWEEP_OCC"); return e ? atoi(e) : 3; }();
     if (occ == 2)
-        dense_wta5x5_sweep_kernel<2><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border);
+        dense_wta5x5_sweep_kernel<2, WORDS, MIRROR><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border);
     else
-        dense_wta5x5_sweep_kernel<3><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border);
+        dense_wta5x5_sweep_kernel<3, WORDS, MIRROR><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border);
     SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_sweep_kernel");
     return SVX_OK;
+}
+
+// words: 32-bit words per census descriptor (1 or 2); mirror: search in the other view (see sweep_chunk).
+static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
+                        float *disparity, int write_border, int words = 1, int mirror = 0) {
+    if (max_disp > SW_DMASK + 1 || cols < SW_T + 4 || rows < 5) {
+        dim3 grid(svx_cdiv(cols, 64), svx_cdiv(rows, 4), n_frames);
+        if (words == 1) dense_wta5x5_plain_kernel<1><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity, write_border, mirror);
+        else dense_wta5x5_plain_kernel<2><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity, write_border, mirror);
+        SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_plain_kernel");
+        return SVX_OK;
+    }
+    if (words == 1) return mirror ? launch_sweep<1, true>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border)
+                                  : launch_sweep<1, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border);
+    return mirror ? launch_sweep<2, true>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border)
+                  : launch_sweep<2, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border);
 }
 
 SVX_API int svx_dense_wta5x5(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right,
@@ -364,4 +400,123 @@ SVX_API int svx_dense_census_wta_u8(svx_ctx *ctx, const uint8_t *left, const uin
     rc = svx_census5x5_u8(ctx, right, cr, rows, cols, n_frames, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST);
     if (rc) return rc;
     return launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1);
+}
+
+// ---------------------------------------------------------------------------
+// 64-bit descriptors: 9x7 census, dense search in either view, left-right check.
+// The reference has no 9x7 census and no dense left-right check; these generalise its 5x5 dense
+// matcher (denseCensusStereo.cpp:87-131) along the lines of its generic NxN census
+// (denseCensusStereo/CensusTransform.cpp:33-67) and of libelas' consistency check (elas/elas.cpp:909-979).
+constexpr int C97_W = 64, C97_H = 16, C97_HX = 4, C97_HY = 3, C97_PITCH = C97_W + 2 * C97_HX;
+
+// Descriptor of pixel (x, y), 4 <= x < cols-4, 3 <= y < rows-3: neighbour (dy, dx), dy = -3..3, dx = -4..4, has
+// index (dy+3)*9 + (dx+4) and bit 62 - index; the bit is set when the centre is greater than the neighbour
+// (the centre's own bit, 31, stays 0).  Word 0 holds bits 0..31, word 1 bits 32..62.  All other pixels get 0.
+__global__ __launch_bounds__(256) void census9x7_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, uint2 *__restrict__ out_all) {
+    __shared__ uint8_t tile[(C97_H + 2 * C97_HY) * C97_PITCH];
+    const long n = (long)rows * cols;
+    const uint8_t *img = img_all + (long)blockIdx.z * n;
+    uint2 *out = out_all + (long)blockIdx.z * n;
+    const int x0 = blockIdx.x * C97_W, y0 = blockIdx.y * C97_H;
+    for (int i = threadIdx.x; i < (C97_H + 2 * C97_HY) * C97_PITCH; i += 256) {
+        const int ty = i / C97_PITCH, tx = i - ty * C97_PITCH;
+        const int gy = y0 + ty - C97_HY, gx = x0 + tx - C97_HX;
+        tile[i] = (gy >= 0 && gy < rows && gx >= 0 && gx < cols) ? img[(long)gy * cols + gx] : (uint8_t)0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, x = x0 + lx;
+    if (x >= cols) return;
+#pragma unroll 1
+    for (int ly = threadIdx.x >> 6; ly < C97_H; ly += 4) {
+        const int y = y0 + ly;
+        if (y >= rows) break;
+        uint32_t lo = 0, hi = 0;
+        if (x >= C97_HX && x < cols - C97_HX && y >= C97_HY && y < rows - C97_HY) {
+            const uint8_t *c = &tile[(ly + C97_HY) * C97_PITCH + lx + C97_HX];
+            const uint32_t cv = c[0];
+#pragma unroll
+            for (int dy = -3; dy <= 3; ++dy)
+#pragma unroll
+                for (int dx = -4; dx <= 4; ++dx) {
+                    const int bit = 62 - ((dy + 3) * 9 + (dx + 4));
+                    if (dy == 0 && dx == 0) continue;
+                    const uint32_t f = cv > (uint32_t)c[dy * C97_PITCH + dx] ? 1u : 0u;
+                    if (bit < 32) lo |= f << bit; else hi |= f << (bit - 32);
+                }
+        }
+        out[(long)y * cols + x] = make_uint2(lo, hi);
+    }
+}
+
+SVX_API int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census, int rows, int cols, int n_frames) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, img && census, SVX_ERR_INVALID_ARG, "svx_census9x7_u8: null pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "svx_census9x7_u8: empty image");
+    SVX_REQUIRE(ctx, n_frames <= 65535 && svx_cdiv(rows, C97_H) <= 65535, SVX_ERR_UNSUPPORTED, "svx_census9x7_u8: too many frames or rows per call");
+    census9x7_kernel<<<dim3(svx_cdiv(cols, C97_W), svx_cdiv(rows, C97_H), n_frames), 256, 0, ctx->stream>>>(img, rows, cols, (uint2 *)census);
+    SVX_LAUNCH_CHECK(ctx, "census9x7_kernel");
+    return SVX_OK;
+}
+
+SVX_API int svx_dense_wta(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
+                          int words, int max_disp, int view, float *disparity) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    rc = dense_args_ok(ctx, census_left, census_right, disparity, rows, cols, n_frames, max_disp);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_dense_wta: words must be 1 or 2");
+    SVX_REQUIRE(ctx, view == SVX_VIEW_LEFT || view == SVX_VIEW_RIGHT, SVX_ERR_INVALID_ARG, "svx_dense_wta: bad view");
+    // the right view is the left-view search on the mirrored pair with the images swapped
+    if (view == SVX_VIEW_RIGHT) return launch_dense(ctx, census_right, census_left, rows, cols, n_frames, max_disp, disparity, 1, words, 1);
+    return launch_dense(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disparity, 1, words, 0);
+}
+
+__global__ __launch_bounds__(256) void lr_check_kernel(float *__restrict__ dl_all, const float *__restrict__ dr_all, int rows, int cols,
+                                                       float threshold, float invalid) {
+    const long n = (long)rows * cols;
+    float *dl = dl_all + (long)blockIdx.z * n;
+    const float *dr = dr_all + (long)blockIdx.z * n;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
+    const float d1 = dl[(long)y * cols + x];
+    const int xr = x - (int)d1;
+    // a match whose right pixel falls outside the searched region of the right view cannot be confirmed
+    if (xr < 2 || fabsf(dr[(long)y * cols + xr] - d1) > threshold) dl[(long)y * cols + x] = invalid;
+}
+
+SVX_API int svx_lr_check(svx_ctx *ctx, float *disp_left, const float *disp_right, int rows, int cols, int n_frames,
+                         float threshold, float invalid_value) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, disp_left && disp_right, SVX_ERR_INVALID_ARG, "svx_lr_check: null pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "svx_lr_check: empty image");
+    SVX_REQUIRE(ctx, n_frames <= 65535 && rows <= 65535, SVX_ERR_UNSUPPORTED, "svx_lr_check: too many frames or rows per call");
+    lr_check_kernel<<<dim3(svx_cdiv(cols, 256), rows, n_frames), 256, 0, ctx->stream>>>(disp_left, disp_right, rows, cols, threshold, invalid_value);
+    SVX_LAUNCH_CHECK(ctx, "lr_check_kernel");
+    return SVX_OK;
+}
+
+SVX_API int svx_dense_census9x7_lr_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
+                                      int max_disp, float lr_threshold, float *disparity) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    rc = dense_args_ok(ctx, left, right, disparity, rows, cols, n_frames, max_disp);
+    if (rc) return rc;
+    const size_t n = (size_t)rows * cols * n_frames;
+    const bool lr = lr_threshold >= 0.f;
+    void *ws;
+    rc = svx_ws_reserve(ctx, 4 * n * sizeof(uint32_t) + (lr ? n * sizeof(float) : 0), &ws);
+    if (rc) return rc;
+    uint32_t *cl = (uint32_t *)ws, *cr = cl + 2 * n;
+    float *dr = (float *)(cr + 2 * n);
+    rc = svx_census9x7_u8(ctx, left, cl, rows, cols, n_frames);
+    if (rc) return rc;
+    rc = svx_census9x7_u8(ctx, right, cr, rows, cols, n_frames);
+    if (rc) return rc;
+    rc = launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, 2, 0);
+    if (rc || !lr) return rc;
+    rc = launch_dense(ctx, cr, cl, rows, cols, n_frames, max_disp, dr, 1, 2, 1);
+    if (rc) return rc;
+    return svx_lr_check(ctx, disparity, dr, rows, cols, n_frames, lr_threshold, -1.0f);
 }

@@ -62,6 +62,9 @@ lib.orc_delaunay_check.restype = C.c_int
 lib.orc_delaunay_check.argtypes = [_p, C.c_int, _p, C.c_int]
 lib.orc_point_cloud.restype = C.c_int
 lib.orc_point_cloud.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_double, _p, _p]
+lib.orc_census9x7.argtypes = [_p, C.c_int, C.c_int, _p]
+lib.orc_dense_wta_words.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int]
+lib.orc_lr_check.argtypes = [_p, _p, C.c_int, C.c_int, C.c_float, C.c_float]
 lib.orc_exfast_detect.restype = C.c_int
 lib.orc_exfast_detect.argtypes = [_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _p, _p, C.c_int]
 
@@ -273,6 +276,30 @@ def point_cloud(pts_xy, disp, q, roi=(0, 0), bgr=None, max_range=8000.0):
                             _ptr(bgr) if bgr is not None else None, bgr.shape[1] if bgr is not None else 0, max_range,
                             _ptr(xyz), _ptr(rgb) if rgb is not None else None)
     return xyz[:n], (rgb[:n] if rgb is not None else None)
+
+
+# ---- 64-bit descriptors, right view, left-right check ----
+def census9x7(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty(img.shape + (2,), np.uint32)
+    lib.orc_census9x7(_ptr(img), img.shape[0], img.shape[1], _ptr(out))
+    return out
+
+
+def dense_wta_words(cl, cr, max_disp, view=0, y0=0, y1=None):
+    cl = np.ascontiguousarray(cl, dtype=np.uint32); cr = np.ascontiguousarray(cr, dtype=np.uint32)
+    rows, cols = cl.shape[0], cl.shape[1]
+    words = cl.shape[2] if cl.ndim == 3 else 1
+    out = np.zeros((rows, cols), np.float32)
+    lib.orc_dense_wta_words(_ptr(cl), _ptr(cr), rows, cols, words, max_disp, view, _ptr(out), y0, rows if y1 is None else y1)
+    return out
+
+
+def lr_check(dl, dr, threshold, invalid=-1.0):
+    out = np.ascontiguousarray(dl, dtype=np.float32).copy()
+    dr = np.ascontiguousarray(dr, dtype=np.float32)
+    lib.orc_lr_check(_ptr(out), _ptr(dr), out.shape[0], out.shape[1], threshold, invalid)
+    return out
 
 
 # ---- the formula image of tests/golden/survey_kat.json ----

@@ -106,3 +106,33 @@ def test_exfast_properties():
         assert np.all(np.diff(keys) > 0)
         assert a[:, 0].min() >= 3 and a[:, 0].max() < 77 and a[:, 1].min() >= 3 and a[:, 1].max() < 57
     assert len(O.exfast_detect(np.full((40, 40), 128, np.uint8), 10, 1.0)[0]) == 0
+
+
+def test_right_view_is_the_mirrored_left_view():
+    """Definition check on the oracle itself: right-view map == mirror(left-view map of the mirrored, swapped pair)."""
+    rng = np.random.default_rng(4)
+    cl = rng.integers(0, 1 << 32, size=(20, 70, 2), dtype=np.uint64).astype(np.uint32) & np.uint32(0x11111111)
+    cr = np.roll(cl, -4, axis=1)
+    right = O.dense_wta_words(cl, cr, 24, view=1)
+    mirrored = O.dense_wta_words(cr[:, ::-1].copy(), cl[:, ::-1].copy(), 24, view=0)[:, ::-1]
+    assert np.array_equal(right, mirrored)
+
+
+def test_census9x7_hand_example():
+    img = np.full((9, 11), 100, np.uint8)
+    img[1, 1] = 5                      # neighbour (dy,dx) = (-3,-4) of pixel (4,5): index 0 -> bit 62
+    img[4, 6] = 7                      # neighbour (0,+1): index 3*9+5 = 32 -> bit 30
+    c = O.census9x7(img)
+    assert c[4, 5, 1] == 1 << (62 - 32) and c[4, 5, 0] == 1 << 30
+    assert c[0].sum() == 0 and c[:, :4].sum() == 0 and c[:, -4:].sum() == 0 and c[-3:].sum() == 0
+
+
+def test_lr_check_hand_example():
+    dl = np.zeros((5, 12), np.float32); dr = np.zeros((5, 12), np.float32)
+    dl[2, 8] = 3; dr[2, 5] = 3          # consistent
+    dl[2, 9] = 4; dr[2, 5] = 3          # off by one: kept at threshold 1, dropped at 0
+    dl[2, 3] = 2                         # x_r = 1 < 2: cannot be confirmed
+    out1 = O.lr_check(dl, dr, 1.0)
+    assert out1[2, 8] == 3 and out1[2, 9] == 4 and out1[2, 3] == -1
+    out0 = O.lr_check(dl, dr, 0.0)
+    assert out0[2, 9] == -1 and out0[0, 0] == 0
