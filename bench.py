@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark of the census stereo-matching hot path on MI355X.
 
-One step = one pass of the fused hot path (u8 -> census 5x5 on both images -> 5x5-aggregated Hamming
-WTA over D disparities) over one batch of synthetic rectified frames that is already resident in HBM.
+One step = one pass of the fused hot path over one batch of synthetic rectified frames that is already
+resident in HBM.  Variants (--variant):
+  9x7lr  (default) u8 -> 9x7 census (64-bit) on both images -> 5x5-aggregated Hamming WTA in the left
+         view -> the same in the right view -> left-right check: the "dense census 9x7 + Hamming/WTA +
+         L-R check" configuration.
+  9x7    the same without the right view and the check.
+  5x5    u8 -> 5x5 census (24-bit, the reference's transform) -> WTA, the reference-pinned variant.
 Workload: KITTI-size 1242x375 frames cropped to the multiple-of-16 size 1232x368 the reference works
 on, D = 128, `--frames` frames per GPU (weak scaling: every rank owns its own batch; no collective
 in the data path).  Prints ONE JSON line on rank 0.
@@ -39,7 +44,35 @@ def parse():
     ap.add_argument("--max-disp", type=int, default=128)
     ap.add_argument("--cpu-frames", type=float, default=8.0, help="frames of CPU-baseline work (0 disables)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--variant", choices=["9x7lr", "9x7", "5x5"], default="9x7lr")
+    ap.add_argument("--lr-threshold", type=float, default=1.0)
     return ap.parse_args()
+
+
+def cpu_baseline_9x7(left, right, D, n_frames_work, lr, lr_threshold):
+    """Times the CPU oracle of the 9x7 variants on a bounded sample of rows, 1 thread."""
+    import oracle_lib as O
+    rows, cols = left.shape
+    t0 = time.perf_counter()
+    cl, cr = O.census9x7(left), O.census9x7(right)
+    t_census = time.perf_counter() - t0
+    nrows = max(1, min(rows - 4, int(round(n_frames_work * (rows - 4)))))
+    t0 = time.perf_counter()
+    want = O.dense_wta_words(cl, cr, D, 0, 2, 2 + nrows)
+    if lr:
+        want_r = O.dense_wta_words(cl, cr, D, 1, 2, 2 + nrows)
+        want = O.lr_check(want, want_r, lr_threshold, -1.0)
+    t_wta = time.perf_counter() - t0
+    frames = nrows / float(rows - 4)
+    secs = t_wta + t_census * frames
+    return {
+        "value": round(rows * cols * D * frames / secs / 1e6, 2),
+        "unit": "Mpix*disp/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%.2f frames of %dx%d D=%d (9x7 census of both images + dense 5x5-aggregated WTA%s), oracle/svx_oracle.c, 1 thread, %.1f s"
+                  % (frames, cols, rows, D, ", both views + left-right check" if lr else "", secs),
+    }, want, nrows
 
 
 def cpu_baseline(left, right, D, n_frames_work):
@@ -105,8 +138,15 @@ def main():
 
     barrier = sharding.barrier
 
+    variant = args.variant
+    words = 1 if variant == "5x5" else 2
+    lr = variant == "9x7lr"
+
     def step():
-        ctx.dense_census_wta(left, right, D, out=disp)
+        if variant == "5x5":
+            ctx.dense_census_wta(left, right, D, out=disp)
+        else:
+            ctx.dense_census9x7_lr(left, right, D, lr_threshold=args.lr_threshold if lr else -1.0, out=disp)
 
     for _ in range(args.warmup):
         step()
@@ -145,7 +185,7 @@ def main():
         n_k = max(5, min(args.steps, 20))
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        timed = S.dominant_kernel_timer(ctx, left, right, D, disp)
+        timed = S.dominant_kernel_timer(ctx, left, right, D, disp, words)
         timed()                                   # warm
         e0.record(stream)
         for _ in range(n_k):
@@ -153,7 +193,7 @@ def main():
         e1.record(stream)
         e1.synchronize()
         k_ms = e0.elapsed_time(e1) / n_k
-        valu_ops = 2.0 * pixdisp_per_frame * F                      # v_xor + v_bcnt per descriptor word per pix*disp
+        valu_ops = 2.0 * words * pixdisp_per_frame * F              # v_xor + v_bcnt per descriptor word per pix*disp
         hbm_bytes = float(rows * cols * F * (1 + 1 + 4))            # u8 left + u8 right in, f32 disparity out
         try:
             measured_peak = ctx.probe_valu_rate(0, 4, 20000) / 1e12
@@ -163,7 +203,7 @@ def main():
         traffic = None   # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            if tj["kernel"] == S.DOMINANT_KERNEL and F == 64 and D == 128:
+            if tj["kernel"] == S.DOMINANT_KERNEL and tj.get("words", 1) == words and F == 64 and D == 128:
                 traffic = (tj["fetch_size_kb"] + tj["write_size_kb"]) * 1024.0
         except Exception:
             traffic = None
@@ -176,6 +216,7 @@ def main():
             "frac": round(achieved / VALU_PEAK_TLOPS, 4),
             "traffic": traffic,
             "kernel_ms": round(k_ms, 4),
+            "launches_per_step": 2 if lr else 1,
             "algorithmic_ops_per_launch": valu_ops,
             "measured_xor_bcnt_peak": None if measured_peak is None else round(measured_peak, 2),
             "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,
@@ -190,12 +231,18 @@ def main():
         cpu = None
         parity = "not checked"
         if args.cpu_frames > 0 and world == 1:
-            cpu, want, nrows = cpu_baseline(ls[0], rs[0], D, args.cpu_frames)
+            step()                                 # the timing launches above reused `disp`
+            torch.cuda.synchronize(dev)
+            if variant == "5x5":
+                cpu, want, nrows = cpu_baseline(ls[0], rs[0], D, args.cpu_frames)
+            else:
+                cpu, want, nrows = cpu_baseline_9x7(ls[0], rs[0], D, args.cpu_frames / (8.0 if lr else 4.0), lr, args.lr_threshold)
             got = disp[0].cpu().numpy()
             same = bool(np.array_equal(got[2:2 + nrows], want[2:2 + nrows]))
             parity = "bit-exact vs oracle on frame 0 rows 2..%d" % (1 + nrows) if same else "MISMATCH vs oracle on frame 0"
         out = {
-            "metric": "Mpix*disp/s, dense census 5x5 + Hamming WTA, 1242x375 (cropped 1232x368) @128 disp",
+            "metric": "Mpix*disp/s, dense census %s + Hamming WTA%s, 1242x375 (cropped 1232x368) @%d disp"
+                      % ("5x5" if variant == "5x5" else "9x7", " + L-R check" if lr else "", D),
             "value": round(value, 1),
             "unit": "Mpix*disp/s",
             "n_gpus": world,
@@ -205,12 +252,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32",
+            "dtype": "u32" if words == 1 else "u64",
             "data": "synthetic",
             "frames_per_s": round(frames_per_s, 1),
-            "config": {"workload": "configs[1] reference-pinned variant: fused u8->census5x5(24-bit)->5x5 Hamming WTA, "
-                                   "%dx%d (1242x375 cropped to /16), D=%d, %d frames/GPU/step, frame-sharded, no collective"
-                                   % (cols, rows, D, F),
+            "config": {"workload": "configs[1] %s, %dx%d (1242x375 cropped to /16), D=%d, %d frames/GPU/step, frame-sharded, no collective"
+                                   % ({"5x5": "reference-pinned variant: fused u8->census5x5(24-bit)->5x5-aggregated Hamming WTA",
+                                       "9x7": "without the check: fused u8->census9x7(64-bit)->5x5-aggregated Hamming WTA",
+                                       "9x7lr": "fused u8->census9x7(64-bit)->5x5-aggregated Hamming WTA in both views->left-right check"}[variant],
+                                      cols, rows, D, F),
+                       "variant": variant,
                        "frames_per_gpu": F, "rows": rows, "cols": cols, "max_disp": D,
                        "parallelism": "frames x%d" % world},
             "roofline": roofline,

@@ -493,9 +493,12 @@ def delaunay(pts_xy):
 DOMINANT_KERNEL = "dense_wta5x5_sweep_kernel"
 
 
-def dominant_kernel_timer(ctx, left, right, max_disp, disp):
+def dominant_kernel_timer(ctx, left, right, max_disp, disp, words=1):
     """Returns a zero-argument callable that launches exactly the dominant kernel of the hot path
-    (the dense WTA) once, on inputs prepared here, so that it can be bracketed by stream events."""
+    (the dense WTA, left view) once, on inputs prepared here, so that it can be bracketed by stream events."""
+    if words == 2:
+        cl, cr = ctx.census9x7(left), ctx.census9x7(right)
+        return lambda: ctx.dense_wta(cl, cr, max_disp, VIEW_LEFT, 2, out=disp)
     cl = ctx.census5x5(left, CENSUS_SSE24 | CENSUS_ZERO_REST)
     cr = ctx.census5x5(right, CENSUS_SSE24 | CENSUS_ZERO_REST)
     return lambda: ctx.dense_wta5x5(cl, cr, max_disp, out=disp)

@@ -125,18 +125,27 @@ __device__ __forceinline__ uint32_t reduce16(const uint32_t (&k)[SW_T], int lane
 // One census row of the sweep, phase 1: fold the row into the running column sums.
 // cl: the 20 left words of the row (wavefront-uniform, in SGPRs); rp: this lane's view of the staged right
 // words, skewed by its disparity (lane l reads column xq + 63 - l + j).
-// WORDS = 32-bit words per census descriptor; word w of the staged row sits SW_SLOT_WORDS further on.
+// WORDS = 32-bit words per census descriptor; a staged row holds the descriptors of consecutive columns
+// back to back (WORDS words each), so a two-word descriptor is one 64-bit LDS access.
 template <int WORDS>
 __device__ __forceinline__ void sweep_row_accumulate(SweepState &st, const uint32_t (&cl)[SW_C * WORDS], const uint32_t *__restrict__ rp) {
-    uint32_t cr[WORDS][SW_C];
+    uint32_t cr[SW_C][WORDS];
 #pragma unroll
-    for (int w = 0; w < WORDS; ++w)
+    for (int j = 0; j < SW_C; ++j) {
+        if (WORDS == 1) {
+            cr[j][0] = rp[j];
+        } else {
+            const uint2 v = *reinterpret_cast<const uint2 *>(rp + 2 * j);
+            cr[j][0] = v.x; cr[j][WORDS - 1] = v.y;
+        }
+    }
 #pragma unroll
-        for (int j = 0; j < SW_C; ++j) cr[w][j] = rp[w * SW_SLOT_WORDS + j];
+    for (int j = 0; j < SW_C; ++j) {
+        st.C[j] += (uint32_t)__builtin_popcount(cl[j * WORDS] ^ cr[j][0]);
 #pragma unroll
-    for (int j = 0; j < SW_C; ++j)
-#pragma unroll
-        for (int w = 0; w < WORDS; ++w) st.C[j] += (uint32_t)__builtin_popcount(cl[j * WORDS + w] ^ cr[w][j]);
+        for (int w = 1; w < WORDS; ++w)   // keep the accumulating popcount: left to itself the compiler sums the counts with extra adds
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(st.C[j]) : "v"(cl[j * WORDS + w] ^ cr[j][w]), "v"(st.C[j]));
+    }
 }
 
 // Phase 2: form the 16 window keys and reduce them over the lanes.
@@ -213,14 +222,16 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
             g.b[0] = vb.x; g.b[WORDS - 1] = vb.y;
         }
     };
-    uint32_t *const st_w0 = &stage[0][lane], *const st_w1 = &stage[0][64 + (lane & 31)];
-    const uint32_t *const st_r = &stage[0][63 - lane];
+    uint32_t *const st_w0 = &stage[0][lane * WORDS], *const st_w1 = &stage[0][(64 + (lane & 31)) * WORDS];
+    const uint32_t *const st_r = &stage[0][(63 - lane) * WORDS];
     constexpr int SLOT_STRIDE = WORDS * SW_SLOT_WORDS;
     auto stash = [&](int slot, const Fetched &g) {
-#pragma unroll
-        for (int w = 0; w < WORDS; ++w) {
-            st_w0[slot * SLOT_STRIDE + w * SW_SLOT_WORDS] = g.a[w];
-            st_w1[slot * SLOT_STRIDE + w * SW_SLOT_WORDS] = g.b[w];     // lanes l and l+32 store the same word
+        if (WORDS == 1) {
+            st_w0[slot * SLOT_STRIDE] = g.a[0];
+            st_w1[slot * SLOT_STRIDE] = g.b[0];     // lanes l and l+32 store the same word
+        } else {
+            *reinterpret_cast<uint2 *>(st_w0 + slot * SLOT_STRIDE) = make_uint2(g.a[0], g.a[WORDS - 1]);
+            *reinterpret_cast<uint2 *>(st_w1 + slot * SLOT_STRIDE) = make_uint2(g.b[0], g.b[WORDS - 1]);
         }
         __builtin_amdgcn_wave_barrier();            // the rows are read back by other lanes of this wavefront
     };
@@ -279,7 +290,7 @@ template <int WAVES_PER_SIMD, int WORDS, bool MIRROR>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                                  int rows, int cols, int max_disp, int strip_rows, int n_xblocks,
                                                                  float *__restrict__ disp_all, int write_border) {
-    __shared__ uint32_t lds_stage[4][SW_SLOTS][WORDS * SW_SLOT_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_stage[4][SW_SLOTS][WORDS * SW_SLOT_WORDS];
     __shared__ uint32_t lds_best[2][SW_MAX_STRIP][SW_T];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
