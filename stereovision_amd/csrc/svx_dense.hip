@@ -423,7 +423,7 @@ constexpr int C97_W = 64, C97_H = 16, C97_HX = 4, C97_HY = 3, C97_PITCH = C97_W 
 // Descriptor of pixel (x, y), 4 <= x < cols-4, 3 <= y < rows-3: neighbour (dy, dx), dy = -3..3, dx = -4..4, has
 // index (dy+3)*9 + (dx+4) and bit 62 - index; the bit is set when the centre is greater than the neighbour
 // (the centre's own bit, 31, stays 0).  Word 0 holds bits 0..31, word 1 bits 32..62.  All other pixels get 0.
-__global__ __launch_bounds__(256) void census9x7_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, uint2 *__restrict__ out_all) {
+__global__ __launch_bounds__(256) void census9x7_pixel_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, uint2 *__restrict__ out_all) {
     __shared__ uint8_t tile[(C97_H + 2 * C97_HY) * C97_PITCH];
     const long n = (long)rows * cols;
     const uint8_t *img = img_all + (long)blockIdx.z * n;
@@ -459,14 +459,70 @@ __global__ __launch_bounds__(256) void census9x7_kernel(const uint8_t *__restric
     }
 }
 
+// Fast variant for cols % 4 == 0 and 4-byte aligned frames: a lane owns four adjacent pixels of four rows.
+// The image is staged as dwords (every staged dword lies wholly inside or wholly outside the frame); the twelve
+// bytes x-4..x+7 of a window row are three aligned dwords, and each descriptor bit costs one SDWA byte compare
+// plus one add-with-carry that shifts it in (generated blocks, tools/gen_census97.py).
+#include "svx_census97_px.inc"
+constexpr int C97T_W = 256, C97T_H = 16, C97T_LROW = C97T_W / 4 + 2 + 1;   // dwords per staged row (+1 pad)
+
+__global__ __launch_bounds__(256) void census9x7_tile_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, uint32_t *__restrict__ out_all) {
+    __shared__ uint32_t tile[(C97T_H + 6) * C97T_LROW];
+    const long n = (long)rows * cols;
+    const uint8_t *img = img_all + (long)blockIdx.z * n;
+    uint32_t *out = out_all + (long)blockIdx.z * n * 2;
+    const int x0 = blockIdx.x * C97T_W, y0 = blockIdx.y * C97T_H;
+    for (int i = threadIdx.x; i < (C97T_H + 6) * C97T_LROW; i += 256) {
+        const int r = i / C97T_LROW, k = i - r * C97T_LROW;
+        const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * k;
+        uint32_t v = 0u;
+        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = *reinterpret_cast<const uint32_t *>(img + (long)gy * cols + gx);
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = x0 + lane * 4;
+    if (x >= cols) return;
+    uint32_t R[10][3];                 // staged rows wave*4 .. wave*4+9 = image rows y-3 .. y+6 of the lane's first row y
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t *q = tile + (wave * 4 + r) * C97T_LROW + lane;
+        R[r][0] = q[0]; R[r][1] = q[1]; R[r][2] = q[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = y0 + wave * 4 + j;
+        if (y >= rows) break;
+        uint32_t hi[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
+        if (y >= 3 && y < rows - 3) {
+            const uint32_t (*W)[3] = R + j;
+            C97_PX0(hi[0], lo[0], W);
+            C97_PX1(hi[1], lo[1], W);
+            C97_PX2(hi[2], lo[2], W);
+            C97_PX3(hi[3], lo[3], W);
+            if (x < 4) hi[0] = lo[0] = hi[1] = lo[1] = hi[2] = lo[2] = hi[3] = lo[3] = 0u;            // cols % 4 == 0: the border
+            if (x >= cols - 4) hi[0] = lo[0] = hi[1] = lo[1] = hi[2] = lo[2] = hi[3] = lo[3] = 0u;    // columns are whole lanes
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(out + ((long)y * cols + x) * 2);
+        o[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+        o[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+    }
+}
+
 SVX_API int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census, int rows, int cols, int n_frames) {
     int rc = svx_enter(ctx);
     if (rc) return rc;
     SVX_REQUIRE(ctx, img && census, SVX_ERR_INVALID_ARG, "svx_census9x7_u8: null pointer");
     SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "svx_census9x7_u8: empty image");
     SVX_REQUIRE(ctx, n_frames <= 65535 && svx_cdiv(rows, C97_H) <= 65535, SVX_ERR_UNSUPPORTED, "svx_census9x7_u8: too many frames or rows per call");
-    census9x7_kernel<<<dim3(svx_cdiv(cols, C97_W), svx_cdiv(rows, C97_H), n_frames), 256, 0, ctx->stream>>>(img, rows, cols, (uint2 *)census);
-    SVX_LAUNCH_CHECK(ctx, "census9x7_kernel");
+    const bool fast = (cols % 4 == 0) && (((uintptr_t)img & 3u) == 0) && (((uintptr_t)census & 15u) == 0);
+    if (fast) {
+        census9x7_tile_kernel<<<dim3(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97T_H), n_frames), 256, 0, ctx->stream>>>(img, rows, cols, census);
+        SVX_LAUNCH_CHECK(ctx, "census9x7_tile_kernel");
+    } else {
+        census9x7_pixel_kernel<<<dim3(svx_cdiv(cols, C97_W), svx_cdiv(rows, C97_H), n_frames), 256, 0, ctx->stream>>>(img, rows, cols, (uint2 *)census);
+        SVX_LAUNCH_CHECK(ctx, "census9x7_pixel_kernel");
+    }
     return SVX_OK;
 }
 
