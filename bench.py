@@ -202,8 +202,8 @@ def main():
         achieved = valu_ops / (k_ms * 1e-3) / 1e12
         traffic = None   # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            if tj["kernel"] == S.DOMINANT_KERNEL and tj.get("words", 1) == words and F == 64 and D == 128:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_w%d.json" % words)))
+            if tj["kernel"] == S.DOMINANT_KERNEL and tj["words"] == words and F == 64 and D == 128:
                 traffic = (tj["fetch_size_kb"] + tj["write_size_kb"]) * 1024.0
         except Exception:
             traffic = None
