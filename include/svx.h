@@ -285,6 +285,55 @@ int svx_point_cloud(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float 
                     int roi_x, int roi_y, const double *q_host, const uint8_t *bgr, int img_rows, int img_cols,
                     double max_range, double *xyz_out, uint8_t *rgb_out, int capacity, int *n_out_host);
 
+/* ---- the pipeline that calls the census path end to end ----------------------
+ * svx_stereo_parameters mirrors StereoParameters, highPerfStereo/highPerfStereoLib.h:35-70, field for
+ * field (bool -> int, uchar/char kept).  resizeFactor, blurSize and colorMapSliding are carried but unused,
+ * as in the reference (its blur kernel size is (int)applyBlur = 1, highPerfStereoLib.cpp:207, :289-292:
+ * the identity).
+ * svx_high_perf_stereo replaces highPerfStereo(), highPerfStereoLib.h:224-228, .cpp:177-645, for one
+ * rectified pair on the device: crop to multiples of 16, [equalise], Laplacian + |.|, high-gradient
+ * point set, row alterations for the detector, exFAST on both images, 5x5 census, sparse matching,
+ * support-point mesh, then nIters rounds of {plane prior, costEvaluation, disparityRefinement,
+ * supportResampling}, and finally the support points themselves.  disparity_map is rows x cols
+ * (the INPUT size, .cpp:190), in/out: only pixels the reference writes change.  The computed points
+ * (high-gradient points in raster order, then the mesh vertices in insertion order) are written to
+ * points_xy_host; *n_points is their number, at most `capacity` are stored.
+ * Differences from the reference, all outside its own arithmetic: the mesh is libsvx's Delaunay
+ * triangulation instead of Fade2D's (see svx_delaunay); the prior is interpolated when recordFullDisp
+ * is set, but no "disparity<iter>.png" is written (.cpp:565-570); showImages (a display) is refused;
+ * ddepth must be CV_16S (3), the value every caller in the reference passes.  Synchronous. */
+typedef struct svx_stereo_parameters {
+    double uniqueness;
+    int maxDisp;
+    int leftRightStep;
+    int costAggrWindowSize;
+    unsigned char gradThreshold;
+    signed char tLow;
+    signed char tHigh;
+    int nIters;
+    double resizeFactor;
+    int applyBlur;
+    int applyHistEqualization;
+    int blurSize;
+    int kernelSize;
+    int scale;
+    int delta;
+    int ddepth;
+    double adaptivity;
+    int minThreshold;
+    int traceLines;
+    int nbLines;
+    int lineSize;
+    int invertRows;
+    int nbRows;
+    int recordFullDisp;
+    int showImages;
+    int colorMapSliding;
+} svx_stereo_parameters;
+int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols,
+                         const svx_stereo_parameters *parameters, float *disparity_map,
+                         int32_t *points_xy_host, int capacity, int *n_points);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------
  * Sustained issue rate, in lane-instructions per second, of the VALU pairs the
  * dense matcher is built from, with `waves_per_simd` wavefronts resident per

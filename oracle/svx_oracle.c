@@ -435,21 +435,39 @@ ORC_API void orc_plane_fit(const double xy_d[9], float abc[3]) {
  * Pixels covered by no triangle keep their previous value. */
 ORC_API void orc_plane_prior_raster(const int32_t *tri_xy /* ntri*6 */, const float *tri_abc /* ntri*3 */,
                                     int ntri, int rows, int cols, float *prior) {
-    for (int y = 0; y < rows; ++y)
-        for (int x = 0; x < cols; ++x)
-            for (int t = 0; t < ntri; ++t) {
-                const int32_t *v = tri_xy + 6 * t;
-                const int64_t area2 = (int64_t)(v[2] - v[0]) * (v[5] - v[1]) - (int64_t)(v[3] - v[1]) * (v[4] - v[0]);
-                if (area2 == 0) continue;   /* degenerate triangles own nothing */
+    /* triangles in list order, each over its bounding box; a pixel already owned is skipped, which is
+     * the same as asking every pixel for its first containing triangle */
+    unsigned char *owned = (unsigned char *)calloc((size_t)rows * cols, 1);
+    if (!owned) return;
+    for (int t = 0; t < ntri; ++t) {
+        const int32_t *v = tri_xy + 6 * t;
+        const int64_t area2 = (int64_t)(v[2] - v[0]) * (v[5] - v[1]) - (int64_t)(v[3] - v[1]) * (v[4] - v[0]);
+        if (area2 == 0) continue;   /* degenerate triangles own nothing */
+        int x0 = v[0], x1 = v[0], y0 = v[1], y1 = v[1];
+        for (int k = 1; k < 3; ++k) {
+            if (v[2 * k] < x0) x0 = v[2 * k];
+            if (v[2 * k] > x1) x1 = v[2 * k];
+            if (v[2 * k + 1] < y0) y0 = v[2 * k + 1];
+            if (v[2 * k + 1] > y1) y1 = v[2 * k + 1];
+        }
+        if (x0 < 0) x0 = 0;
+        if (y0 < 0) y0 = 0;
+        if (x1 > cols - 1) x1 = cols - 1;
+        if (y1 > rows - 1) y1 = rows - 1;
+        const float *p = tri_abc + 3 * t;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                if (owned[(long)y * cols + x]) continue;
                 const int64_t e0 = (int64_t)(v[2] - v[0]) * (y - v[1]) - (int64_t)(v[3] - v[1]) * (x - v[0]);
                 const int64_t e1 = (int64_t)(v[4] - v[2]) * (y - v[3]) - (int64_t)(v[5] - v[3]) * (x - v[2]);
                 const int64_t e2 = (int64_t)(v[0] - v[4]) * (y - v[5]) - (int64_t)(v[1] - v[5]) * (x - v[4]);
                 if ((e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0)) {
-                    const float *p = tri_abc + 3 * t;
+                    owned[(long)y * cols + x] = 1;
                     prior[(long)y * cols + x] = (float)((double)p[0] * (double)x + (double)p[1] * (double)y + (double)p[2]);
-                    break;
                 }
             }
+    }
+    free(owned);
 }
 
 /* ----------------------------------------------------------------- a13 --

@@ -59,8 +59,32 @@ EXPORTS = {
     "svx_delaunay": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]),
     "svx_mesh_plane_prior": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_i)]),
     "svx_point_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _i, C.POINTER(_i)]),
+    "svx_high_perf_stereo": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
 }
+
+
+class StereoParameters(C.Structure):
+    """svx_stereo_parameters of include/svx.h: StereoParameters of highPerfStereo/highPerfStereoLib.h:35-70, field for field."""
+    _fields_ = [("uniqueness", C.c_double), ("maxDisp", _i), ("leftRightStep", _i), ("costAggrWindowSize", _i),
+                ("gradThreshold", C.c_ubyte), ("tLow", C.c_byte), ("tHigh", C.c_byte), ("nIters", _i),
+                ("resizeFactor", C.c_double), ("applyBlur", _i), ("applyHistEqualization", _i), ("blurSize", _i),
+                ("kernelSize", _i), ("scale", _i), ("delta", _i), ("ddepth", _i),
+                ("adaptivity", C.c_double), ("minThreshold", _i), ("traceLines", _i), ("nbLines", _i), ("lineSize", _i),
+                ("invertRows", _i), ("nbRows", _i), ("recordFullDisp", _i), ("showImages", _i), ("colorMapSliding", _i)]
+
+    @classmethod
+    def reference_defaults(cls, **over):
+        """The values the reference's callers hard-code (highPerfStereo/main.cpp:38-72), recordFullDisp on."""
+        p = cls(uniqueness=0.5, maxDisp=70, leftRightStep=1, costAggrWindowSize=11, gradThreshold=70, tLow=2, tHigh=10,
+                nIters=1, resizeFactor=1.0, applyBlur=0, applyHistEqualization=0, blurSize=3, kernelSize=3, scale=1, delta=0,
+                ddepth=3, adaptivity=0.25, minThreshold=3, traceLines=0, nbLines=20, lineSize=2, invertRows=0, nbRows=20,
+                recordFullDisp=1, showImages=0, colorMapSliding=60)
+        for k, v in over.items():
+            if k not in dict(cls._fields_):
+                raise KeyError(k)
+            setattr(p, k, v)
+        return p
 
 
 class SvxError(RuntimeError):
@@ -452,6 +476,26 @@ class Context:
         self._call("svx_mesh_plane_prior", pts.ctypes.data_as(_vp), len(pts), _dptr(disparities), disparities.shape[0],
                    disparities.shape[1], _dptr(prior), C.byref(n))
         return prior, n.value
+
+    # ---- the full pipeline ----
+    def high_perf_stereo(self, left, right, params, disparity_map):
+        """highPerfStereo() on one rectified pair: disparity_map ([rows, cols] float32, in/out) is updated in place;
+        returns the computed points [n, 2] int32 (host): the high-gradient points, then the mesh vertices."""
+        t = self._torch
+        _check_dev(left, t.uint8, "left"); _check_dev(right, t.uint8, "right"); _check_dev(disparity_map, t.float32, "disparity_map")
+        if left.dim() != 2:
+            raise ValueError("high_perf_stereo works on one [rows, cols] pair")
+        if left.shape != right.shape:
+            raise SvxError(-2, "Input images do not have the same dimensions!")
+        if left.shape != disparity_map.shape:
+            raise SvxError(-2, "disparity map do not have the same dimensions as the input images!")
+        rows, cols = left.shape
+        cap = 2 * rows * cols
+        pts = np.zeros((cap, 2), np.int32)
+        n = _i(0)
+        self._call("svx_high_perf_stereo", _dptr(left), _dptr(right), rows, cols, C.byref(params), _dptr(disparity_map),
+                   pts.ctypes.data_as(_vp), cap, C.byref(n))
+        return pts[:min(n.value, cap)].copy()
 
     # ---- point cloud ----
     def point_cloud(self, pts_xy, disparity_map, q, roi=(0, 0), bgr=None, max_range=8000.0, capacity=None):

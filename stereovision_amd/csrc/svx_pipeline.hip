@@ -1,0 +1,237 @@
+// highPerfStereo(): the support-point / plane-prior pipeline that calls the census path end to end
+// (highPerfStereo/highPerfStereoLib.cpp:177-645), as host glue over the libsvx entry points.  Every image
+// stays on the device; the host sees key points, matches, the support-point list and the occupancy grid,
+// as the reference's host code does.
+#include "svx_common.hpp"
+#include <algorithm>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+// disparities(y,x) = d for the support points, in list order (highPerfStereoLib.cpp:436-445)
+__global__ void scatter_support_kernel(const int32_t *__restrict__ xy, const float *__restrict__ d, int n, int cols, float *__restrict__ map) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) map[(long)xy[2 * i + 1] * cols + xy[2 * i]] = d[i];
+}
+
+// disparityMap(p) = int(disparities(p)) for every mesh vertex (highPerfStereoLib.cpp:628-637)
+__global__ void vertex_disparities_kernel(const int32_t *__restrict__ xy, int n, int cols, const float *__restrict__ disparities,
+                                          float *__restrict__ final_disp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const long p = (long)xy[2 * i + 1] * cols + xy[2 * i];
+        final_disp[p] = (float)(int)disparities[p];
+    }
+}
+
+// Bump allocator over one device allocation (the context's workspace belongs to the entry points called below).
+struct Arena {
+    char *base = nullptr;
+    size_t used = 0, cap = 0;
+    template <class T> T *take(size_t n) {
+        used = (used + 255) & ~(size_t)255;
+        T *p = reinterpret_cast<T *>(base + used);
+        used += n * sizeof(T);
+        return p;
+    }
+};
+
+struct ArenaGuard {
+    void *p = nullptr;
+    ~ArenaGuard() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+#define SVX_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
+
+SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols,
+                                 const svx_stereo_parameters *prm, float *disparity_map,
+                                 int32_t *points_xy_host, int capacity, int *n_points) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, left && right, SVX_ERR_EMPTY, "Input images are empty!");                         // .cpp:184-185
+    SVX_REQUIRE(ctx, prm && disparity_map && n_points, SVX_ERR_INVALID_ARG, "svx_high_perf_stereo: null pointer");
+    SVX_REQUIRE(ctx, capacity >= 0 && (capacity == 0 || points_xy_host), SVX_ERR_INVALID_ARG, "svx_high_perf_stereo: bad point buffer");
+    SVX_REQUIRE(ctx, rows >= 16 && cols >= 16, SVX_ERR_EMPTY, "svx_high_perf_stereo: images smaller than 16x16 crop to nothing");
+    SVX_REQUIRE(ctx, prm->ddepth == 3, SVX_ERR_UNSUPPORTED, "svx_high_perf_stereo: ddepth must be CV_16S (3)");
+    SVX_REQUIRE(ctx, prm->nIters >= 0 && prm->maxDisp >= 1, SVX_ERR_INVALID_ARG, "svx_high_perf_stereo: bad nIters or maxDisp");
+    SVX_REQUIRE(ctx, !prm->showImages, SVX_ERR_UNSUPPORTED, "svx_high_perf_stereo: showImages needs a display; use recordFullDisp");
+    *n_points = 0;
+
+    const int R = 16 * (rows / 16), Cc = 16 * (cols / 16);                                              // .cpp:245
+    const size_t n = (size_t)R * Cc;
+    const int t_low = (signed char)prm->tLow, t_high = (signed char)prm->tHigh;
+    unsigned occ = 64;                                                                                  // .cpp:449
+    const size_t max_cells = (size_t)(R + 1) * (Cc + 1);     // the grid shrinks to 1-pixel cells after six halvings
+    size_t cells_needed = (size_t)(R / 64 + 1) * (Cc / 64 + 1);
+    {
+        unsigned g = occ;
+        for (int it = 1; it < prm->nIters; ++it) { g = std::max(1u, g / 2); cells_needed = std::max(cells_needed, (size_t)(R / g + 1) * (Cc / g + 1)); }
+        cells_needed = std::min(cells_needed, max_cells);
+    }
+
+    // one device allocation for every intermediate image and list; laid out twice (measure, then place)
+    uint8_t *L, *Rr, *La, *Ra, *grad;
+    uint32_t *cL, *cR;
+    int32_t *pts, *kpl, *kpr, *conf_x, *conf_y, *inv_x, *inv_y, *rs_xy;
+    float *respl, *respr, *disparities, *final_disp, *conf_d, *rs_d;
+    int8_t *costs, *final_costs, *conf_c, *inv_c;
+    uint8_t *rs_valid;
+    auto layout = [&](Arena &a) {
+        L = a.take<uint8_t>(n); Rr = a.take<uint8_t>(n); La = a.take<uint8_t>(n); Ra = a.take<uint8_t>(n); grad = a.take<uint8_t>(n);
+        cL = a.take<uint32_t>(n); cR = a.take<uint32_t>(n);
+        pts = a.take<int32_t>(2 * n); kpl = a.take<int32_t>(2 * n); kpr = a.take<int32_t>(2 * n);
+        respl = a.take<float>(n); respr = a.take<float>(n);
+        disparities = a.take<float>(n); final_disp = a.take<float>(n);
+        costs = a.take<int8_t>(n); final_costs = a.take<int8_t>(n);
+        conf_x = a.take<int32_t>(cells_needed); conf_y = a.take<int32_t>(cells_needed);
+        inv_x = a.take<int32_t>(cells_needed); inv_y = a.take<int32_t>(cells_needed);
+        conf_d = a.take<float>(cells_needed);
+        conf_c = a.take<int8_t>(cells_needed); inv_c = a.take<int8_t>(cells_needed);
+        rs_xy = a.take<int32_t>(4 * cells_needed); rs_d = a.take<float>(2 * cells_needed); rs_valid = a.take<uint8_t>(2 * cells_needed);
+    };
+    Arena measure;
+    layout(measure);
+    Arena a;
+    a.cap = measure.used + 256;
+    ArenaGuard guard;
+    if (hipMalloc(&guard.p, a.cap) != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: %zu bytes of device memory", a.cap);
+    a.base = (char *)guard.p;
+    layout(a);
+
+    // crop to multiples of 16, equalise, gradient, high-gradient point set (.cpp:245-280)
+    SVX_TRY(svx_crop16(ctx, left, rows, cols, 1, L));
+    SVX_TRY(svx_crop16(ctx, right, rows, cols, 1, Rr));
+    if (prm->applyHistEqualization) {
+        SVX_TRY(svx_equalize_hist(ctx, L, L, R, Cc, 1));
+        SVX_TRY(svx_equalize_hist(ctx, Rr, Rr, R, Cc, 1));
+    }
+    SVX_TRY(svx_laplacian_abs(ctx, L, grad, R, Cc, 1, prm->kernelSize, (double)prm->scale, (double)prm->delta));
+    int off[2] = {0, 0};
+    SVX_TRY(svx_high_gradient_points(ctx, grad, R, Cc, 1, prm->gradThreshold, pts, (int)n, off));
+    const int n_hg = off[1];
+    // .cpp:289-292: the blur kernel size is `(int)applyBlur` = 1 (.cpp:207), i.e. the blur is the identity
+
+    // altered copies for the detector only (.cpp:296-335)
+    SVX_HIP(ctx, hipMemcpyAsync(La, L, n, hipMemcpyDeviceToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(Ra, Rr, n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (prm->invertRows || prm->traceLines) {
+        SVX_TRY(svx_alter_rows(ctx, La, R, Cc, 1, prm->invertRows, prm->nbRows, prm->traceLines, prm->nbLines, prm->lineSize));
+        SVX_TRY(svx_alter_rows(ctx, Ra, R, Cc, 1, prm->invertRows, prm->nbRows, prm->traceLines, prm->nbLines, prm->lineSize));
+    }
+
+    // exFAST on the altered copies (left with suppression, right without, .cpp:358-359), census of the plain ones (.cpp:371-387)
+    int offl[2], offr[2];
+    SVX_TRY(svx_exfast_detect(ctx, La, R, Cc, 1, prm->minThreshold, (float)prm->adaptivity, SVX_EXFAST_NONMAX, kpl, respl, (int)n, offl));
+    SVX_TRY(svx_exfast_detect(ctx, Ra, R, Cc, 1, prm->minThreshold, (float)prm->adaptivity, 0, kpr, respr, (int)n, offr));
+    const int nl = offl[1], nr = offr[1];
+    SVX_TRY(svx_census5x5_u8(ctx, L, cL, R, Cc, 1, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST));
+    SVX_TRY(svx_census5x5_u8(ctx, Rr, cR, R, Cc, 1, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST));
+
+    // sparse matching of the key points (.cpp:354-355, :390)
+    std::vector<int32_t> hl(2 * (size_t)nl), hr(2 * (size_t)nr);
+    if (nl) SVX_HIP(ctx, hipMemcpyAsync(hl.data(), kpl, hl.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (nr) SVX_HIP(ctx, hipMemcpyAsync(hr.data(), kpr, hr.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<float> fl(hl.begin(), hl.end()), fr(hr.begin(), hr.end());
+    fl.push_back(0.f); fr.push_back(0.f);     // never read: keeps data() non-null for empty lists
+    std::vector<int32_t> ml(nl ? nl : 1), mr(nl ? nl : 1);
+    std::vector<int16_t> mc(nl ? nl : 1);
+    int n_rec = 0;
+    SVX_TRY(svx_sparse_match(ctx, cL, cR, R, Cc, fl.data(), nl, fr.data(), nr, prm->maxDisp, 1.0f, (float)prm->uniqueness, prm->leftRightStep,
+                             ml.data(), mr.data(), mc.data(), &n_rec));
+
+    // support points of the mesh, in insertion order, repeated positions dropped (.cpp:434-445)
+    std::vector<int32_t> sup;                 // x,y pairs
+    std::vector<float> sup_d;
+    std::unordered_set<int64_t> seen;
+    auto insert_point = [&](int x, int y) {
+        if (seen.insert((int64_t)y * Cc + x).second) { sup.push_back(x); sup.push_back(y); }
+    };
+    std::vector<int32_t> sxy;
+    for (int i = 0; i < n_rec; ++i) {
+        if (mr[i] < 0) continue;
+        const int x = hl[2 * ml[i]], y = hl[2 * ml[i] + 1];
+        sxy.push_back(x); sxy.push_back(y);
+        sup_d.push_back((float)x - (float)hr[2 * mr[i]]);       // SparseMatch::disparity(), sparsematch.h:27-29
+        insert_point(x, y);
+    }
+    SVX_HIP(ctx, hipMemsetAsync(disparities, 0, n * sizeof(float), ctx->stream));
+    auto upload_scatter = [&](const std::vector<int32_t> &xy, const std::vector<float> &d) -> int {
+        const int m = (int)d.size();
+        if (!m) return SVX_OK;
+        void *tmp = nullptr;
+        if (hipMalloc(&tmp, (size_t)m * 12) != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: support staging");
+        int32_t *dxy = (int32_t *)tmp;
+        float *dd = (float *)((char *)tmp + (size_t)m * 8);
+        hipError_t e = hipMemcpyAsync(dxy, xy.data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dd, d.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            scatter_support_kernel<<<svx_cdiv(m, 256), 256, 0, ctx->stream>>>(dxy, dd, m, Cc, disparities);
+            e = hipGetLastError();
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+        return e == hipSuccess ? SVX_OK : svx_fail(ctx, SVX_ERR_HIP, "svx_high_perf_stereo: support upload: %s", hipGetErrorString(e));
+    };
+    SVX_TRY(upload_scatter(sxy, sup_d));
+
+    // final maps: the caller's disparity map (input-sized, .cpp:190) restricted to the cropped frame; costs start at 25 (.cpp:448)
+    SVX_HIP(ctx, hipMemcpy2DAsync(final_disp, (size_t)Cc * 4, disparity_map, (size_t)cols * 4, (size_t)Cc * 4, R, hipMemcpyDeviceToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemsetAsync(final_costs, 25, n, ctx->stream));
+
+    for (int iter = 1; iter <= prm->nIters; ++iter) {                                                   // .cpp:451
+        // plane table and interpolation of the prior over the whole frame (.cpp:454-466, :532-554)
+        if (prm->recordFullDisp) {
+            int n_tri = 0;
+            SVX_TRY(svx_mesh_plane_prior(ctx, sup.data(), (int)(sup.size() / 2), disparities, R, Cc, disparities, &n_tri));
+        }
+        SVX_HIP(ctx, hipMemsetAsync(costs, t_high & 0xff, n, ctx->stream));                             // .cpp:573
+        SVX_TRY(svx_cost_eval(ctx, cL, cR, R, Cc, pts, n_hg, disparities, costs));                      // .cpp:574
+        SVX_TRY(svx_refine(ctx, pts, n_hg, disparities, costs, R, Cc, t_low, t_high, occ, final_disp, final_costs,
+                           conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c));                       // .cpp:575-576
+        if (iter != prm->nIters) {                                                                      // .cpp:616-621
+            const int gw = Cc / (int)occ + 1, gh = R / (int)occ + 1;
+            const size_t nc = (size_t)gw * gh;
+            SVX_TRY(svx_support_resampling(ctx, cL, cR, R, Cc, 5, prm->costAggrWindowSize, gw, gh, conf_x, conf_y, conf_d, conf_c,
+                                           inv_x, inv_y, inv_c, t_low, t_high, prm->maxDisp, disparities, rs_xy, rs_d, rs_valid));
+            std::vector<int32_t> hxy(4 * nc);
+            std::vector<uint8_t> hv(2 * nc);
+            SVX_HIP(ctx, hipMemcpyAsync(hxy.data(), rs_xy, hxy.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            SVX_HIP(ctx, hipMemcpyAsync(hv.data(), rs_valid, hv.size(), hipMemcpyDeviceToHost, ctx->stream));
+            SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (size_t s = 0; s < 2 * nc; ++s)
+                if (hv[s]) insert_point(hxy[2 * s], hxy[2 * s + 1]);
+            occ = std::max(1u, occ / 2);
+        }
+    }
+
+    // the support points themselves end up in the map, truncated to integers, and in the point list (.cpp:624-637)
+    const int n_sup = (int)(sup.size() / 2);
+    if (n_sup) {
+        void *tmp = nullptr;
+        if (hipMalloc(&tmp, (size_t)n_sup * 8) != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: vertex staging");
+        hipError_t e = hipMemcpyAsync(tmp, sup.data(), (size_t)n_sup * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            vertex_disparities_kernel<<<svx_cdiv(n_sup, 256), 256, 0, ctx->stream>>>((const int32_t *)tmp, n_sup, Cc, disparities, final_disp);
+            e = hipGetLastError();
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_HIP, "svx_high_perf_stereo: vertex pass: %s", hipGetErrorString(e));
+    }
+    SVX_HIP(ctx, hipMemcpy2DAsync(disparity_map, (size_t)cols * 4, final_disp, (size_t)Cc * 4, (size_t)Cc * 4, R, hipMemcpyDeviceToDevice, ctx->stream));
+
+    // computed points: the high-gradient set in raster order, then the mesh vertices
+    *n_points = n_hg + n_sup;
+    const int take_hg = std::min(n_hg, capacity);
+    if (take_hg) SVX_HIP(ctx, hipMemcpyAsync(points_xy_host, pts, (size_t)take_hg * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_sup && n_hg + i < capacity; ++i) {
+        points_xy_host[2 * (size_t)(n_hg + i)] = sup[2 * i];
+        points_xy_host[2 * (size_t)(n_hg + i) + 1] = sup[2 * i + 1];
+    }
+    return SVX_OK;
+}

@@ -1,0 +1,97 @@
+"""GPU parity of the full highPerfStereo() pipeline (BASELINE configs[2]) through the C ABI against the
+oracle composition of tests/oracle_pipeline.py, bit-exact: disparity map, computed points, and the
+intermediate counts.  Parity status: the pipeline's OpenCV steps and the mesh are unpinned on reference
+outputs (OpenCV and Fade2D are not available); the census / matching / refinement steps are the pinned
+ones.  Both sides use the same triangulation (svx_delaunay, itself checked against the Delaunay
+definition in tests/test_mesh_cpu.py)."""
+import numpy as np
+import pytest
+
+import oracle_pipeline as OP
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import stereovision_amd as S
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    c = S.Context(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_both(ctx, left, right, params, init=0.0):
+    import stereovision_amd as S
+    dm = np.full(left.shape, init, np.float32)
+    want_pts, info = OP.high_perf_stereo(left, right, params, dm, S.delaunay)
+    got_map = dev(np.full(left.shape, init, np.float32))
+    got_pts = ctx.high_perf_stereo(dev(left), dev(right), params, got_map)
+    return got_pts, got_map.cpu().numpy(), want_pts, dm, info
+
+
+@pytest.mark.parametrize("rows,cols,seed,over", [
+    (375, 1242, 0, dict(maxDisp=70, nIters=1)),
+    (375, 1242, 1, dict(maxDisp=70, nIters=2, applyHistEqualization=1)),
+    (375, 1242, 2, dict(maxDisp=100, nIters=3, gradThreshold=40, invertRows=1, nbRows=20, traceLines=1, nbLines=20, lineSize=2)),
+    (120, 250, 3, dict(maxDisp=32, nIters=2, gradThreshold=30)),
+    (64, 64, 4, dict(maxDisp=16, nIters=4, gradThreshold=20, costAggrWindowSize=5)),
+    (100, 200, 5, dict(maxDisp=32, nIters=2, recordFullDisp=0)),
+    (48, 80, 6, dict(maxDisp=16, nIters=8, gradThreshold=10)),
+])
+def test_pipeline_matches_oracle(ctx, rows, cols, seed, over):
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    p = S.StereoParameters.reference_defaults(**over)
+    left, right, _ = synth.stereo_pair(rows, cols, min(p.maxDisp, 64), seed)
+    got_pts, got_map, want_pts, want_map, info = run_both(ctx, left, right, p)
+    assert np.array_equal(got_pts, want_pts), info
+    assert np.array_equal(got_map, want_map)
+    # the run exercised the stages it is meant to cover
+    assert info["n_high_grad"] > 0
+    if rows >= 100:
+        assert info["n_matches"] >= 3 and info["n_support"] >= info["n_matches"]
+    # the part of the caller's map outside the 16-pixel crop is untouched
+    assert np.all(got_map[16 * (rows // 16):] == 0) and np.all(got_map[:, 16 * (cols // 16):] == 0)
+
+
+def test_pipeline_recovers_the_scene(ctx):
+    """On a pair generated from a known piecewise-planar field, most accepted high-gradient pixels carry that field."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    rows, cols = 375, 1242
+    left, right, field = synth.stereo_pair(rows, cols, 64, seed=7)
+    p = S.StereoParameters.reference_defaults(maxDisp=70, nIters=3, gradThreshold=50)
+    got_map = dev(np.zeros((rows, cols), np.float32))
+    pts = ctx.high_perf_stereo(dev(left), dev(right), p, got_map)
+    m = got_map.cpu().numpy()
+    xs, ys = pts[:, 0], pts[:, 1]
+    written = m[ys, xs] != 0
+    assert written.sum() > 1000
+    err = np.abs(m[ys, xs] - field[ys, xs])[written]
+    assert (err <= 1.0).mean() > 0.8, (err <= 1.0).mean()
+
+
+def test_pipeline_keeps_caller_values_and_errors(ctx):
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    left, right, _ = synth.stereo_pair(64, 96, 16, seed=8)
+    p = S.StereoParameters.reference_defaults(maxDisp=16, nIters=1, gradThreshold=255)   # no pixel exceeds 255
+    got_pts, got_map, want_pts, want_map, info = run_both(ctx, left, right, p, init=7.5)
+    assert info["n_high_grad"] == 0
+    assert np.array_equal(got_pts, want_pts) and np.array_equal(got_map, want_map)
+    with pytest.raises(S.SvxError, match="same dimensions"):
+        ctx.high_perf_stereo(dev(left), dev(right[:, :80]), p, dev(np.zeros(left.shape, np.float32)))
+    with pytest.raises(S.SvxError, match="disparity map"):
+        ctx.high_perf_stereo(dev(left), dev(right), p, dev(np.zeros((64, 80), np.float32)))
+    with pytest.raises(S.SvxError, match="showImages"):
+        ctx.high_perf_stereo(dev(left), dev(right), S.StereoParameters.reference_defaults(showImages=1), dev(np.zeros(left.shape, np.float32)))
+    tiny = dev(np.zeros((8, 8), np.uint8))
+    with pytest.raises(S.SvxError):
+        ctx.high_perf_stereo(tiny, tiny, p, dev(np.zeros((8, 8), np.float32)))
