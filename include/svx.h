@@ -217,6 +217,17 @@ int svx_lr_check(svx_ctx *ctx, float *disp_left, const float *disp_right, int ro
 int svx_dense_census9x7_lr_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
                               int max_disp, float lr_threshold, float *disparity);
 
+/* Sub-pixel refinement of a left-view map (no counterpart in the reference, which has no sub-pixel step
+ * for census matches).  For 2 <= x < cols-2, 2 <= y < rows-2 holding an integer disparity d >= 1 with
+ * d+1 <= max_disp-1 and x-(d+1) >= 5: c(k) = the 5x5-aggregated Hamming cost at disparity k,
+ * den = c(d-1) - 2c(d) + c(d+1); when den > 0 the value becomes (float)d + (float)(c(d-1)-c(d+1)) / (float)(2 den).
+ * Every other value (invalidated pixels, d = 0, range ends, flat cost curves) stays as it is.
+ * svx_dense_census9x7_subpixel_u8 = svx_dense_census9x7_lr_u8 followed by this step on the same descriptors. */
+int svx_subpixel_refine(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
+                        int words, int max_disp, float *disparity);
+int svx_dense_census9x7_subpixel_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
+                                    int max_disp, float lr_threshold, float *disparity);
+
 /* ---- steps either side of the census path ----------------------------------
  * Pre-processing of highPerfStereo(), highPerfStereoLib.cpp:245-335.  Its
  * arithmetic is OpenCV's (not part of the reference tree); the entry points

@@ -1000,3 +1000,32 @@ ORC_API void orc_lr_check(float *dl, const float *dr, int rows, int cols, float 
             if (xr < 2 || fabsf(dr[(long)y * cols + xr] - d) > threshold) dl[(long)y * cols + x] = invalid;
         }
 }
+
+/* Sub-pixel refinement of a left-view disparity map (build-defined: the reference has no sub-pixel step
+ * for census matches; its only fractional disparities are the plane-interpolated floats of
+ * highPerfStereoLib.cpp:69-73).  For 2 <= x < cols-2, 2 <= y < rows-2 with an integer disparity d >= 1 whose
+ * neighbours d-1 and d+1 are both admissible for the search of orc_dense_wta_words (d+1 <= maxDisp-1 and
+ * x-(d+1) >= 5): with c(k) the 5x5-aggregated Hamming cost at disparity k,
+ *   den = c(d-1) - 2 c(d) + c(d+1);   den > 0:  disp = (float)d + (float)(c(d-1) - c(d+1)) / (float)(2 den)
+ * (one float division, one float addition); otherwise, and for every other pixel (negative = invalidated
+ * values included), the value is left as it is.  Values that are not integers are left alone too. */
+ORC_API void orc_subpixel_refine(const uint32_t *cl, const uint32_t *cr, int rows, int cols, int words, int maxDisp, float *disp) {
+    for (int y = 2; y < rows - 2; ++y)
+        for (int x = 2; x < cols - 2; ++x) {
+            const float f = disp[(long)y * cols + x];
+            const int d = (int)f;
+            if (!(f >= 1.0f) || (float)d != f || d + 1 > maxDisp - 1 || x - (d + 1) < 5) continue;
+            int c[3];
+            for (int k = 0; k < 3; ++k) {
+                const int xr = x - (d - 1 + k);
+                int cost = 0;
+                for (int m = -2; m <= 2; ++m)
+                    for (int n = -2; n <= 2; ++n)
+                        for (int w = 0; w < words; ++w)
+                            cost += __builtin_popcount(cl[((long)(y + m) * cols + x + n) * words + w] ^ cr[((long)(y + m) * cols + xr + n) * words + w]);
+                c[k] = cost;
+            }
+            const int den = c[0] - 2 * c[1] + c[2];
+            if (den > 0) disp[(long)y * cols + x] = (float)d + (float)(c[0] - c[2]) / (float)(2 * den);
+        }
+}

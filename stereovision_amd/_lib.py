@@ -49,6 +49,8 @@ EXPORTS = {
     "svx_dense_wta": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "svx_lr_check": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float]),
     "svx_dense_census9x7_lr_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_float, _vp]),
+    "svx_subpixel_refine": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "svx_dense_census9x7_subpixel_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_float, _vp]),
     "svx_crop16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "svx_equalize_hist": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "svx_laplacian_abs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_double, C.c_double]),
@@ -334,6 +336,27 @@ class Context:
             out = t.empty(left.shape, dtype=t.float32, device=left.device)
         _check_dev(out, t.float32, "out")
         self._call("svx_dense_census9x7_lr_u8", _dptr(left), _dptr(right), r, c, f, int(max_disp), float(lr_threshold), _dptr(out))
+        return out
+
+    def subpixel_refine(self, census_left, census_right, max_disp, disparity, words=1):
+        """In place on `disparity` (left view)."""
+        t = self._torch
+        _check_dev(census_left, t.int32, "census_left"); _check_dev(census_right, t.int32, "census_right")
+        _check_dev(disparity, t.float32, "disparity")
+        f, r, c = _frames(disparity)
+        self._call("svx_subpixel_refine", _dptr(census_left), _dptr(census_right), r, c, f, int(words), int(max_disp), _dptr(disparity))
+        return disparity
+
+    def dense_census9x7_subpixel(self, left, right, max_disp, lr_threshold=1.0, out=None):
+        t = self._torch
+        _check_dev(left, t.uint8, "left"); _check_dev(right, t.uint8, "right")
+        if left.shape != right.shape:
+            raise SvxError(-2, "Mismatching image sizes")
+        f, r, c = _frames(left)
+        if out is None:
+            out = t.empty(left.shape, dtype=t.float32, device=left.device)
+        _check_dev(out, t.float32, "out")
+        self._call("svx_dense_census9x7_subpixel_u8", _dptr(left), _dptr(right), r, c, f, int(max_disp), float(lr_threshold), _dptr(out))
         return out
 
     # ---- a9 ----

@@ -380,3 +380,70 @@ inline void denseEpipolarMatching(const MatU32 &censusLeft, const MatU32 &census
     svx::Runtime::check(svx_dense_wta5x5(svx::Runtime::ctx(), dl.d, dr.d, rows, cols, 1, maxDisparity, dd.d));
     dd.download(finalDisp);
 }
+
+// ---- highPerfStereo/highPerfStereoLib.h:35-70 ---------------------------------------------------------
+class StereoParameters {
+public:
+    // Stereo matching parameters
+    double uniqueness;
+    int maxDisp;
+    int leftRightStep;
+    int costAggrWindowSize;
+    unsigned char gradThreshold;
+    char tLow;
+    char tHigh;
+    int nIters;
+    double resizeFactor;
+    bool applyBlur;
+    bool applyHistEqualization;
+    int blurSize;
+    // Laplace parameters (gradient calculation)
+    int kernelSize;
+    int scale;
+    int delta;
+    int ddepth;
+    // Feature detection parameters
+    double adaptivity;
+    int minThreshold;
+    bool traceLines;
+    int nbLines;
+    int lineSize;
+    bool invertRows;
+    int nbRows;
+    // Misc. parameters
+    bool recordFullDisp;
+    bool showImages;
+    int colorMapSliding;
+};
+
+// highPerfStereoLib.h:224-228  highPerfStereo(leftImg, rightImg, parameters, disparityMap, computedPoints)
+// Errors as highPerfStereoLib.cpp:184-191.  The computed points are appended, as in the reference.
+template <class MatU8, class MatF32, class PointVec>
+inline void highPerfStereo(const MatU8 &leftImg, const MatU8 &rightImg, const StereoParameters &parameters,
+                           MatF32 &disparityMap, PointVec &highGradPoints) {
+    if (leftImg.data == 0 || rightImg.data == 0) throw sparsestereo::Exception("Input images are empty!");
+    if (leftImg.cols != rightImg.cols || leftImg.rows != rightImg.rows)
+        throw sparsestereo::Exception("Input images do not have the same dimensions!");
+    if (leftImg.cols != disparityMap.cols || leftImg.rows != disparityMap.rows)
+        throw sparsestereo::Exception("disparity map do not have the same dimensions as the input images!");
+    const int rows = leftImg.rows, cols = leftImg.cols;
+    svx_stereo_parameters p;
+    p.uniqueness = parameters.uniqueness; p.maxDisp = parameters.maxDisp; p.leftRightStep = parameters.leftRightStep;
+    p.costAggrWindowSize = parameters.costAggrWindowSize; p.gradThreshold = parameters.gradThreshold;
+    p.tLow = (signed char)parameters.tLow; p.tHigh = (signed char)parameters.tHigh; p.nIters = parameters.nIters;
+    p.resizeFactor = parameters.resizeFactor; p.applyBlur = parameters.applyBlur; p.applyHistEqualization = parameters.applyHistEqualization;
+    p.blurSize = parameters.blurSize; p.kernelSize = parameters.kernelSize; p.scale = parameters.scale; p.delta = parameters.delta;
+    p.ddepth = parameters.ddepth; p.adaptivity = parameters.adaptivity; p.minThreshold = parameters.minThreshold;
+    p.traceLines = parameters.traceLines; p.nbLines = parameters.nbLines; p.lineSize = parameters.lineSize;
+    p.invertRows = parameters.invertRows; p.nbRows = parameters.nbRows; p.recordFullDisp = parameters.recordFullDisp;
+    p.showImages = parameters.showImages; p.colorMapSliding = parameters.colorMapSliding;
+    svx::DeviceImage<uint8_t> dl(rows, cols), dr(rows, cols);
+    svx::DeviceImage<float> dd(rows, cols);
+    dl.upload(leftImg); dr.upload(rightImg); dd.upload(disparityMap);
+    std::vector<int32_t> xy(4 * (size_t)rows * cols);
+    int n = 0;
+    svx::Runtime::check(svx_high_perf_stereo(svx::Runtime::ctx(), dl.d, dr.d, rows, cols, &p, dd.d, xy.data(), (int)(xy.size() / 2), &n));
+    dd.download(disparityMap);
+    typedef typename PointVec::value_type P;
+    for (int i = 0; i < n; ++i) highGradPoints.push_back(P(xy[2 * i], xy[2 * i + 1]));
+}

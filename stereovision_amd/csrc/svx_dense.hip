@@ -564,8 +564,72 @@ SVX_API int svx_lr_check(svx_ctx *ctx, float *disp_left, const float *disp_right
     return SVX_OK;
 }
 
+// Sub-pixel refinement (no counterpart in the reference): parabola through the aggregated costs at d-1, d, d+1.
+template <int WORDS>
+__global__ __launch_bounds__(256) void subpixel_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
+                                                       int rows, int cols, int max_disp, float *__restrict__ disp_all) {
+    const long n = (long)rows * cols;
+    const uint32_t *cl = cl_all + (long)blockIdx.z * n * WORDS;
+    const uint32_t *cr = cr_all + (long)blockIdx.z * n * WORDS;
+    float *disp = disp_all + (long)blockIdx.z * n;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
+    const float f = disp[(long)y * cols + x];
+    const int d = (int)f;
+    if (!(f >= 1.0f) || (float)d != f || d + 1 > max_disp - 1 || x - (d + 1) < 5) return;
+    int c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+    for (int m = -2; m <= 2; ++m) {
+        const uint32_t *lrow = cl + ((long)(y + m) * cols + x) * WORDS;
+        const uint32_t *rrow = cr + ((long)(y + m) * cols + x - d) * WORDS;
+#pragma unroll
+        for (int k = -2; k <= 2; ++k)
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) {
+                const uint32_t l = lrow[k * WORDS + w];
+                c0 += popc32(l ^ rrow[(k + 1) * WORDS + w]);      // disparity d-1: right column x-d+1
+                c1 += popc32(l ^ rrow[k * WORDS + w]);
+                c2 += popc32(l ^ rrow[(k - 1) * WORDS + w]);      // disparity d+1
+            }
+    }
+    const int den = c0 - 2 * c1 + c2;
+    if (den > 0) disp[(long)y * cols + x] = (float)d + __fdiv_rn((float)(c0 - c2), (float)(2 * den));
+}
+
+static int launch_subpixel(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp, float *disparity) {
+    dim3 grid(svx_cdiv(cols, 256), rows, n_frames);
+    if (words == 1) subpixel_kernel<1><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity);
+    else subpixel_kernel<2><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity);
+    SVX_LAUNCH_CHECK(ctx, "subpixel_kernel");
+    return SVX_OK;
+}
+
+SVX_API int svx_subpixel_refine(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
+                                int words, int max_disp, float *disparity) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    rc = dense_args_ok(ctx, census_left, census_right, disparity, rows, cols, n_frames, max_disp);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_subpixel_refine: words must be 1 or 2");
+    SVX_REQUIRE(ctx, rows <= 65535, SVX_ERR_UNSUPPORTED, "svx_subpixel_refine: too many rows per call");
+    return launch_subpixel(ctx, census_left, census_right, rows, cols, n_frames, words, max_disp, disparity);
+}
+
+static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
+                                int max_disp, float lr_threshold, int subpixel, float *disparity);
+
 SVX_API int svx_dense_census9x7_lr_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
                                       int max_disp, float lr_threshold, float *disparity) {
+    return dense_census9x7_impl(ctx, left, right, rows, cols, n_frames, max_disp, lr_threshold, 0, disparity);
+}
+
+SVX_API int svx_dense_census9x7_subpixel_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
+                                            int max_disp, float lr_threshold, float *disparity) {
+    return dense_census9x7_impl(ctx, left, right, rows, cols, n_frames, max_disp, lr_threshold, 1, disparity);
+}
+
+static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
+                                int max_disp, float lr_threshold, int subpixel, float *disparity) {
     int rc = svx_enter(ctx);
     if (rc) return rc;
     rc = dense_args_ok(ctx, left, right, disparity, rows, cols, n_frames, max_disp);
@@ -582,8 +646,16 @@ SVX_API int svx_dense_census9x7_lr_u8(svx_ctx *ctx, const uint8_t *left, const u
     rc = svx_census9x7_u8(ctx, right, cr, rows, cols, n_frames);
     if (rc) return rc;
     rc = launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, 2, 0);
-    if (rc || !lr) return rc;
-    rc = launch_dense(ctx, cr, cl, rows, cols, n_frames, max_disp, dr, 1, 2, 1);
     if (rc) return rc;
-    return svx_lr_check(ctx, disparity, dr, rows, cols, n_frames, lr_threshold, -1.0f);
+    if (lr) {
+        rc = launch_dense(ctx, cr, cl, rows, cols, n_frames, max_disp, dr, 1, 2, 1);
+        if (rc) return rc;
+        rc = svx_lr_check(ctx, disparity, dr, rows, cols, n_frames, lr_threshold, -1.0f);
+        if (rc) return rc;
+    }
+    if (subpixel) {
+        SVX_REQUIRE(ctx, rows <= 65535, SVX_ERR_UNSUPPORTED, "svx_dense_census9x7_subpixel_u8: too many rows per call");
+        rc = launch_subpixel(ctx, cl, cr, rows, cols, n_frames, 2, max_disp, disparity);
+    }
+    return rc;
 }

@@ -104,6 +104,46 @@ int main() {
         stereo.match(censusLeft, censusRight, kl, kr, &matches);
         CHECK(matches.size() == kl.size());
         for (size_t i = 0; i < matches.size(); ++i) CHECK(matches[i].disparity() == 4.0f);
+
+        // highPerfStereo(): a shifted-noise pair (disparity 9), the reference's parameter values
+        {
+            const int HR = 100, HC = 210;                 // cropped to 96 x 208 inside
+            svx::Image<unsigned char> hl(HR, HC), hr(HR, HC);
+            uint32_t lcg = 12345u;
+            for (int y = 0; y < HR; ++y)
+                for (int x = 0; x < HC; ++x) { lcg = lcg * 1664525u + 1013904223u; hr(y, x) = (unsigned char)(lcg >> 24); }
+            for (int y = 0; y < HR; ++y)
+                for (int x = 0; x < HC; ++x) hl(y, x) = x >= 9 ? hr(y, x - 9) : (unsigned char)(x * 37 + y);
+            StereoParameters prm;
+            prm.uniqueness = 0.5; prm.maxDisp = 32; prm.leftRightStep = 1; prm.costAggrWindowSize = 11; prm.gradThreshold = 70;
+            prm.tLow = 2; prm.tHigh = 10; prm.nIters = 2; prm.resizeFactor = 1; prm.applyBlur = true; prm.applyHistEqualization = true;
+            prm.blurSize = 5; prm.kernelSize = 3; prm.scale = 1; prm.delta = 0; prm.ddepth = 3 /* CV_16S */;
+            prm.adaptivity = 0.25; prm.minThreshold = 3; prm.traceLines = false; prm.nbLines = 20; prm.lineSize = 2;
+            prm.invertRows = false; prm.nbRows = 50; prm.recordFullDisp = true; prm.showImages = false; prm.colorMapSliding = 60;
+            MatF32 dmap(HR, HC, 0.0f);
+            std::vector<svx::Point> computed(1, svx::Point(-1, -1));     // results are appended
+            highPerfStereo(hl, hr, prm, dmap, computed);
+            CHECK(computed.size() > 100 && computed[0].x == -1);
+            size_t written = 0, right9 = 0;
+            for (size_t i = 1; i < computed.size(); ++i) {
+                const float d = dmap(computed[i].y, computed[i].x);
+                if (d != 0.0f) { ++written; if (std::fabs(d - 9.0f) <= 1.0f) ++right9; }
+            }
+            CHECK(written > 100 && right9 * 10 >= written * 8);
+            for (int x = 0; x < HC; ++x) CHECK(dmap(HR - 1, x) == 0.0f);       // outside the 16-pixel crop: untouched
+            MatF32 again(HR, HC, 0.0f);
+            std::vector<svx::Point> computed2;
+            highPerfStereo(hl, hr, prm, again, computed2);
+            CHECK(computed2.size() + 1 == computed.size() && std::memcmp(again.data, dmap.data, (size_t)HR * HC * 4) == 0);
+            bool t1 = false, t2 = false, t3 = false;
+            try { svx::Image<unsigned char> other(HR, HC + 16); highPerfStereo(hl, other, prm, dmap, computed); }
+            catch (const Exception &e) { t1 = std::string(e.what()) == "Input images do not have the same dimensions!"; }
+            try { MatF32 small(HR, HC - 16, 0.0f); highPerfStereo(hl, hr, prm, small, computed); }
+            catch (const Exception &e) { t2 = std::string(e.what()) == "disparity map do not have the same dimensions as the input images!"; }
+            try { svx::Image<unsigned char> empty; highPerfStereo(empty, empty, prm, dmap, computed); }
+            catch (const Exception &e) { t3 = std::string(e.what()) == "Input images are empty!"; }
+            CHECK(t1 && t2 && t3);
+        }
     } catch (const std::exception &e) {
         printf("exception: %s\n", e.what());
         return 2;

@@ -65,6 +65,7 @@ lib.orc_point_cloud.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, _p, 
 lib.orc_census9x7.argtypes = [_p, C.c_int, C.c_int, _p]
 lib.orc_dense_wta_words.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int]
 lib.orc_lr_check.argtypes = [_p, _p, C.c_int, C.c_int, C.c_float, C.c_float]
+lib.orc_subpixel_refine.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]
 lib.orc_exfast_detect.restype = C.c_int
 lib.orc_exfast_detect.argtypes = [_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _p, _p, C.c_int]
 
@@ -299,6 +300,14 @@ def lr_check(dl, dr, threshold, invalid=-1.0):
     out = np.ascontiguousarray(dl, dtype=np.float32).copy()
     dr = np.ascontiguousarray(dr, dtype=np.float32)
     lib.orc_lr_check(_ptr(out), _ptr(dr), out.shape[0], out.shape[1], threshold, invalid)
+    return out
+
+
+def subpixel_refine(cl, cr, max_disp, disp):
+    cl = np.ascontiguousarray(cl, dtype=np.uint32); cr = np.ascontiguousarray(cr, dtype=np.uint32)
+    out = np.ascontiguousarray(disp, dtype=np.float32).copy()
+    words = cl.shape[2] if cl.ndim == 3 else 1
+    lib.orc_subpixel_refine(_ptr(cl), _ptr(cr), out.shape[0], out.shape[1], words, max_disp, _ptr(out))
     return out
 
 

@@ -91,3 +91,69 @@ def test_fused_census9x7_lr(ctx, rows, cols, max_disp, thr):
     interior = np.zeros_like(valid); interior[8:-8, max_disp + 8:-8] = True
     # sanity: the synthetic disparity field is recovered on most checked pixels
     assert (np.abs(want - field)[valid & interior] <= 1).mean() > 0.9
+
+
+# ------------------------------------------------------------------ sub-pixel refinement (build-defined)
+SUBPIXEL_TOL = 1e-3   # px, the tolerance BASELINE.json states for sub-pixel disparities; the results are in fact identical
+
+
+@pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (30, 150, 128), (9, 21, 5), (5, 20, 8), (64, 300, 200), (4, 30, 4)])
+@pytest.mark.parametrize("words", [1, 2])
+def test_subpixel_refine_matches_oracle(ctx, rows, cols, max_disp, words):
+    rng = np.random.default_rng(rows * 7 + cols + words)
+    shape = (2, rows, cols) + ((2,) if words == 2 else ())
+    cl = rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32)
+    cr = np.roll(cl, -3, axis=2) ^ (rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x00f10300))
+    # start from the true integer winners, then plant invalidated, fractional, zero and out-of-range values
+    disp = np.stack([O.dense_wta_words(cl[f], cr[f], max_disp, 0) for f in range(2)])
+    mask = rng.random(disp.shape)
+    disp[mask < 0.05] = -1.0
+    disp[(mask >= 0.05) & (mask < 0.10)] += 0.25
+    disp[(mask >= 0.10) & (mask < 0.15)] = float(max_disp - 1)
+    disp[(mask >= 0.15) & (mask < 0.20)] = rng.integers(0, max_disp, size=int(((mask >= 0.15) & (mask < 0.20)).sum()))
+    got = ctx.subpixel_refine(dev_u32(cl), dev_u32(cr), max_disp, dev(disp), words=words).cpu().numpy()
+    changed = 0
+    for f in range(2):
+        want = O.subpixel_refine(cl[f], cr[f], max_disp, disp[f])
+        assert np.max(np.abs(got[f] - want), initial=0.0) <= SUBPIXEL_TOL
+        assert np.array_equal(got[f], want)
+        changed += int((want != disp[f]).sum())
+    if rows >= 9 and cols > 20:
+        assert changed > 0
+
+
+@pytest.mark.parametrize("rows,cols,max_disp", [(375, 1242, 128), (64, 200, 48)])
+def test_fused_census9x7_subpixel(ctx, rows, cols, max_disp):
+    from stereovision_amd import synth
+    left, right, field = synth.stereo_pair(rows, cols, max_disp, seed=rows + 1)
+    got = ctx.dense_census9x7_subpixel(dev(left), dev(right), max_disp, lr_threshold=1.0).cpu().numpy()
+    cl, cr = O.census9x7(left), O.census9x7(right)
+    want = O.lr_check(O.dense_wta_words(cl, cr, max_disp, 0), O.dense_wta_words(cl, cr, max_disp, 1), 1.0, -1.0)
+    want = O.subpixel_refine(cl, cr, max_disp, want)
+    assert np.max(np.abs(got - want)) <= SUBPIXEL_TOL and np.array_equal(got, want)
+    valid = want >= 0
+    # a winner is a strict minimum on its left and a minimum on its right: the vertex of the parabola lies within half a pixel
+    assert np.all(np.abs(want[valid] - np.rint(want[valid])) <= 0.5)
+    interior = np.zeros_like(valid); interior[8:-8, max_disp + 8:-8] = True
+    assert (np.abs(want - field)[valid & interior] <= 1).mean() > 0.9
+
+
+def test_subpixel_4k_512_disparities(ctx):
+    """configs[4] size (3840x2160, D=512): the fused run against the oracle on a band of rows, and the sub-pixel step
+    against the oracle on the whole frame starting from the device's own integer map."""
+    from stereovision_amd import synth
+    import stereovision_amd as S
+    rows, cols, D = 2160, 3840, 512
+    left, right, _ = synth.stereo_pair(rows, cols, D, seed=99)
+    dl, dr = dev(left), dev(right)
+    cl, cr = ctx.census9x7(dl), ctx.census9x7(dr)
+    integer = ctx.dense_wta(cl, cr, D, S.VIEW_LEFT, 2)
+    refined = ctx.subpixel_refine(cl, cr, D, integer.clone(), words=2).cpu().numpy()
+    hcl, hcr = cl.cpu().numpy().view(np.uint32), cr.cpu().numpy().view(np.uint32)
+    want = O.subpixel_refine(hcl, hcr, D, integer.cpu().numpy())
+    assert np.array_equal(refined, want)
+    y0, y1 = 1000, 1002
+    band = O.dense_wta_words(hcl, hcr, D, 0, y0, y1)
+    assert np.array_equal(integer.cpu().numpy()[y0:y1], band[y0:y1])
+    fused = ctx.dense_census9x7_subpixel(dl, dr, D, lr_threshold=-1.0).cpu().numpy()
+    assert np.array_equal(fused, refined)
