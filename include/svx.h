@@ -296,6 +296,15 @@ int svx_point_cloud(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float 
                     int roi_x, int roi_y, const double *q_host, const uint8_t *bgr, int img_rows, int img_cols,
                     double max_range, double *xyz_out, uint8_t *rgb_out, int capacity, int *n_out_host);
 
+/* Dense variant of svx_point_cloud for whole disparity maps (the consumer of the dense matcher's output):
+ * every pixel of every frame whose disparity is > min_disparity (0 skips unmatched and invalidated
+ * pixels), in raster order, frames concatenated, reprojected and filtered as above.  xyz_out gets three
+ * doubles a point and pix_xy_out (optional) its pixel; frame_offsets_host[f]..[f+1] (n_frames+1 host
+ * ints) delimit frame f; points past `capacity` are counted but not stored.  Synchronous. */
+int svx_dense_point_cloud(svx_ctx *ctx, const float *disparity_map, int rows, int cols, int n_frames, int roi_x, int roi_y,
+                          const double *q_host, float min_disparity, double max_range, double *xyz_out, int32_t *pix_xy_out,
+                          int capacity, int *frame_offsets_host);
+
 /* ---- the pipeline that calls the census path end to end ----------------------
  * svx_stereo_parameters mirrors StereoParameters, highPerfStereo/highPerfStereoLib.h:35-70, field for
  * field (bool -> int, uchar/char kept).  resizeFactor, blurSize and colorMapSliding are carried but unused,

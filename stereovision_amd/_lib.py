@@ -61,6 +61,7 @@ EXPORTS = {
     "svx_delaunay": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]),
     "svx_mesh_plane_prior": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_i)]),
     "svx_point_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _i, C.POINTER(_i)]),
+    "svx_dense_point_cloud": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_double, _vp, _vp, _i, _vp]),
     "svx_high_perf_stereo": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
 }
@@ -499,6 +500,23 @@ class Context:
         self._call("svx_mesh_plane_prior", pts.ctypes.data_as(_vp), len(pts), _dptr(disparities), disparities.shape[0],
                    disparities.shape[1], _dptr(prior), C.byref(n))
         return prior, n.value
+
+    def dense_point_cloud(self, disparity_map, q, roi=(0, 0), min_disparity=0.0, max_range=8000.0, capacity=None, with_pixels=False):
+        """Every pixel with disparity > min_disparity, reprojected by Q and range-filtered, frames concatenated in raster
+        order.  Returns (xyz [n,3] float64 device, pix [n,2] int32 device or None, frame_offsets numpy int32 [frames+1])."""
+        t = self._torch
+        _check_dev(disparity_map, t.float32, "disparity_map")
+        f, r, c = _frames(disparity_map)
+        capacity = f * r * c if capacity is None else int(capacity)
+        qh = np.ascontiguousarray(q, dtype=np.float64).reshape(16)
+        xyz = t.empty((max(capacity, 1), 3), dtype=t.float64, device=disparity_map.device)
+        pix = t.empty((max(capacity, 1), 2), dtype=t.int32, device=disparity_map.device) if with_pixels else None
+        off = np.zeros(f + 1, np.int32)
+        self._call("svx_dense_point_cloud", _dptr(disparity_map), r, c, f, int(roi[0]), int(roi[1]), qh.ctypes.data_as(_vp),
+                   float(min_disparity), float(max_range), _dptr(xyz), _dptr(pix) if pix is not None else None, capacity,
+                   off.ctypes.data_as(_vp))
+        n = min(int(off[-1]), capacity)
+        return xyz[:n], (pix[:n] if pix is not None else None), off
 
     # ---- the full pipeline ----
     def high_perf_stereo(self, left, right, params, disparity_map):

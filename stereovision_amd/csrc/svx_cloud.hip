@@ -63,6 +63,36 @@ struct CloudEmit {
     }
 };
 
+// Dense variant: every pixel whose disparity exceeds a floor, in raster order.
+struct DensePred {
+    QMat q;
+    const float *disp;
+    int rows, cols, roi_x, roi_y;
+    float min_disp;
+    double max_range;
+    __device__ bool operator()(int x, int y, int frame) const {
+        const float d = disp[((long)frame * rows + y) * cols + x];
+        if (!(d > min_disp)) return false;
+        double X, Y, Z;
+        return reproject(q, (double)(x + roi_x), (double)(y + roi_y), (double)d, max_range, X, Y, Z);
+    }
+};
+
+struct DenseEmit {
+    QMat q;
+    const float *disp;
+    int rows, cols, roi_x, roi_y;
+    double max_range;
+    double *xyz;
+    int32_t *pix;
+    __device__ void operator()(unsigned slot, int x, int y, int frame) const {
+        double X, Y, Z;
+        reproject(q, (double)(x + roi_x), (double)(y + roi_y), (double)disp[((long)frame * rows + y) * cols + x], max_range, X, Y, Z);
+        xyz[3 * (size_t)slot] = X; xyz[3 * (size_t)slot + 1] = Y; xyz[3 * (size_t)slot + 2] = Z;
+        if (pix) { pix[2 * (size_t)slot] = x; pix[2 * (size_t)slot + 1] = y; }
+    }
+};
+
 __global__ void cloud_check_points_kernel(const int32_t *__restrict__ pts, int n, int rows, int cols, int roi_x, int roi_y,
                                           int img_rows, int img_cols, int check_img, unsigned *__restrict__ bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,4 +142,25 @@ SVX_API int svx_point_cloud(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, cons
     if (rc) return rc;
     *n_out_host = off[1];
     return SVX_OK;
+}
+
+SVX_API int svx_dense_point_cloud(svx_ctx *ctx, const float *disparity_map, int rows, int cols, int n_frames, int roi_x, int roi_y,
+                                  const double *q_host, float min_disparity, double max_range, double *xyz_out, int32_t *pix_xy_out,
+                                  int capacity, int *frame_offsets_host) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, disparity_map && q_host && frame_offsets_host, SVX_ERR_INVALID_ARG, "svx_dense_point_cloud: null pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "svx_dense_point_cloud: empty disparity map");
+    SVX_REQUIRE(ctx, capacity >= 0 && (capacity == 0 || xyz_out), SVX_ERR_INVALID_ARG, "svx_dense_point_cloud: bad output buffer");
+    DensePred pred;
+    DenseEmit emit;
+    for (int i = 0; i < 16; ++i) pred.q.m[i] = emit.q.m[i] = q_host[i];
+    pred.disp = emit.disp = disparity_map; pred.rows = emit.rows = rows; pred.cols = emit.cols = cols;
+    pred.roi_x = emit.roi_x = roi_x; pred.roi_y = emit.roi_y = roi_y; pred.max_range = emit.max_range = max_range;
+    pred.min_disp = min_disparity;
+    emit.xyz = xyz_out; emit.pix = pix_xy_out;
+    void *ws;
+    rc = svx_ws_reserve(ctx, svx_compact_bytes(rows, n_frames), &ws);
+    if (rc) return rc;
+    return svx_compact_raster(ctx, ws, rows, cols, n_frames, pred, emit, capacity, frame_offsets_host, "dense_point_cloud");
 }

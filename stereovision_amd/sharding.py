@@ -44,3 +44,25 @@ def gather_to_rank0(disp):
     bufs = [torch.empty_like(disp) for _ in range(world_size())] if rank == 0 else None
     dist.gather(disp, bufs, dst=0)
     return bufs
+
+
+def gather_point_clouds_to_rank0(xyz):
+    """Gathers every rank's [n_r, 3] point tensor (n_r differs per rank) to rank 0: first the counts
+    (one all_gather of an int64 per rank), then the payloads, each rank's padded to the largest count so
+    that one fixed-size gather moves them.  Returns (list of [n_r, 3] tensors indexed by rank, counts) on
+    rank 0 and (None, counts) elsewhere."""
+    if world_size() == 1:
+        return [xyz], [int(xyz.shape[0])]
+    rank, world = dist.get_rank(), world_size()
+    n = torch.tensor([xyz.shape[0]], dtype=torch.int64, device=xyz.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+    padded = torch.zeros((m, 3), dtype=xyz.dtype, device=xyz.device)
+    padded[:xyz.shape[0]] = xyz
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, bufs, dst=0)
+    if rank != 0:
+        return None, counts
+    return [bufs[r][:counts[r]] for r in range(world)], counts

@@ -51,9 +51,26 @@ def _worker(rank, world, port, out_dir):
             l2, r2 = synth.stereo_batch(rows, cols, D, frames_per_rank, seed0=r * frames_per_rank)
             want = np.stack([O.dense_wta5x5(O.census5x5(O.u8_to_s8(a)), O.census5x5(O.u8_to_s8(b)), D) for a, b in zip(l2, r2)])
             assert np.array_equal(gathered[r].numpy(), want)
-        open(os.path.join(out_dir, "ok"), "w").write("ok")
     else:
         assert gathered is None
+    # variable-length point clouds (one per rank, different sizes, an empty one included) gathered to rank 0
+    n_mine = [0, 37][rank] if world == 2 else 11 * rank
+    Q = np.array([[1, 0, 0, -30.0], [0, 1, 0, -12.0], [0, 0, 0, 700.0], [0, 0, 1.0 / 0.5, 0]], np.float64)
+    ys, xs = np.nonzero(disp[0] > 0)
+    pts = np.stack([xs, ys], 1).astype(np.int32)[:n_mine]
+    xyz, _ = O.point_cloud(pts, disp[0], Q)
+    clouds, counts = sharding.gather_point_clouds_to_rank0(torch.from_numpy(xyz))
+    assert counts[rank] == len(xyz) and len(counts) == world
+    if rank == 0:
+        for r in range(world):
+            l2, r2 = synth.stereo_batch(rows, cols, D, 1, seed0=r * frames_per_rank)
+            d2 = O.dense_wta5x5(O.census5x5(O.u8_to_s8(l2[0])), O.census5x5(O.u8_to_s8(r2[0])), D)
+            y2, x2 = np.nonzero(d2 > 0)
+            want, _ = O.point_cloud(np.stack([x2, y2], 1).astype(np.int32)[:[0, 37][r]], d2, Q)
+            assert clouds[r].shape == (counts[r], 3) and np.array_equal(clouds[r].numpy(), want)
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    else:
+        assert clouds is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -255,3 +255,28 @@ def test_point_cloud_rejects_points_outside(ctx):
         ctx.point_cloud(dev(np.array([[5, 5]], np.int32)), disp, Q_KITTI, roi=(28, 0), bgr=dev(np.zeros((20, 30, 3), np.uint8)))
     xyz, rgb, k = ctx.point_cloud(dev(np.zeros((0, 2), np.int32)), disp, Q_KITTI)
     assert k == 0
+
+
+@pytest.mark.parametrize("frames,rows,cols", [(1, 375, 1242), (3, 64, 80), (2, 5, 7)])
+def test_dense_point_cloud(ctx, frames, rows, cols):
+    """Every pixel above the disparity floor, frames concatenated in raster order == the point-list routine on that list."""
+    rng = np.random.default_rng(frames * 1000 + rows)
+    disp = (rng.integers(-4, 200, size=(frames, rows, cols)).astype(np.float32) * 0.25)
+    disp[rng.random(disp.shape) < 0.3] = -1.0
+    roi = (5, 2)
+    for min_d, max_range in ((0.0, 8000.0), (10.0, 60.0)):
+        xyz, pix, off = ctx.dense_point_cloud(dev(disp), Q_KITTI, roi, min_d, max_range, with_pixels=True)
+        xyz, pix = xyz.cpu().numpy(), pix.cpu().numpy()
+        assert off[0] == 0 and off[-1] == len(xyz)
+        for f in range(frames):
+            ys, xs = np.nonzero(disp[f] > min_d)
+            pts = np.stack([xs, ys], 1).astype(np.int32)
+            wxyz, _ = O.point_cloud(pts, disp[f], Q_KITTI, roi, None, max_range)
+            assert off[f + 1] - off[f] == len(wxyz)
+            assert np.array_equal(xyz[off[f]:off[f + 1]], wxyz)
+            # the pixels come back in raster order and are the ones the oracle kept
+            p = pix[off[f]:off[f + 1]]
+            key = p[:, 1].astype(np.int64) * cols + p[:, 0]
+            assert np.all(np.diff(key) > 0)
+    xyz, pix, off = ctx.dense_point_cloud(dev(disp), Q_KITTI, capacity=3)
+    assert len(xyz) == min(3, int(off[-1])) and pix is None
