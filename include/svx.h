@@ -204,6 +204,9 @@ int svx_plane_prior_raster(svx_ctx *ctx, const int32_t *tri_xy, const float *tri
  *   (border 0).  SVX_VIEW_RIGHT gives the right image's map: for (x_r, y) scan
  *   x_l = x_r, x_r+1, ... while x_l <= cols-6 and x_l < x_r + max_disp, disparity = x_l - x_r
  *   of the first minimum.
+ * svx_dense_wta_both: both maps of svx_dense_wta in one call.  The cost of (left column x, disparity d) is also the cost
+ *   of right pixel x-d at disparity d, so one sweep over the cost values serves both views: the results are identical
+ *   to the two svx_dense_wta calls.
  * svx_lr_check: for 2 <= x < cols-2, 2 <= y < rows-2: d = disp_left(y,x), x_r = x - (int)d;
  *   disp_left(y,x) = invalid_value when x_r < 2 or |disp_right(y,x_r) - d| > threshold.
  * svx_dense_census9x7_lr_u8: census of both images, left-view search, and for
@@ -212,6 +215,8 @@ enum svx_view { SVX_VIEW_LEFT = 0, SVX_VIEW_RIGHT = 1 };
 int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census, int rows, int cols, int n_frames);
 int svx_dense_wta(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
                   int words, int max_disp, int view, float *disparity);
+int svx_dense_wta_both(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
+                       int words, int max_disp, float *disp_left, float *disp_right);
 int svx_lr_check(svx_ctx *ctx, float *disp_left, const float *disp_right, int rows, int cols, int n_frames,
                  float threshold, float invalid_value);
 int svx_dense_census9x7_lr_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,

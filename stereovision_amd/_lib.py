@@ -47,6 +47,7 @@ EXPORTS = {
     "svx_plane_prior_raster": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "svx_census9x7_u8": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "svx_dense_wta": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "svx_dense_wta_both": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "svx_lr_check": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float]),
     "svx_dense_census9x7_lr_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_float, _vp]),
     "svx_subpixel_refine": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -318,6 +319,19 @@ class Context:
         _check_dev(out, t.float32, "out")
         self._call("svx_dense_wta", _dptr(census_left), _dptr(census_right), r, c, f, int(words), int(max_disp), int(view), _dptr(out))
         return out
+
+    def dense_wta_both(self, census_left, census_right, max_disp, words=1):
+        """Left and right disparity maps from one pass over the cost values: (disp_left, disp_right)."""
+        t = self._torch
+        _check_dev(census_left, t.int32, "census_left"); _check_dev(census_right, t.int32, "census_right")
+        if census_left.shape != census_right.shape:
+            raise SvxError(-2, "Mismatching image sizes")
+        img_shape = census_left.shape[:-1] if words == 2 else census_left.shape
+        f, r, c = (1,) + tuple(img_shape) if len(img_shape) == 2 else tuple(img_shape)
+        dl = t.empty(tuple(img_shape), dtype=t.float32, device=census_left.device)
+        dr = t.empty(tuple(img_shape), dtype=t.float32, device=census_left.device)
+        self._call("svx_dense_wta_both", _dptr(census_left), _dptr(census_right), r, c, f, int(words), int(max_disp), _dptr(dl), _dptr(dr))
+        return dl, dr
 
     def lr_check(self, disp_left, disp_right, threshold, invalid=-1.0):
         """In place on disp_left."""

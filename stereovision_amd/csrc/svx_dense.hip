@@ -150,8 +150,29 @@ __device__ __forceinline__ void sweep_row_accumulate(SweepState &st, const uint3
 
 // Phase 2: form the 16 window keys and reduce them over the lanes.
 // R = row counter modulo 10 (ring slot R % 5, sign (-1)^R).
-template <int R, bool MASKED>
-__device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, uint32_t d, int xlim_base, int dmax) {
+// Right view from the same cost values: the cost of (left column x, disparity d) is also the cost of the right
+// pixel x-d at disparity d, so the right image's winner is the minimum along a diagonal of the (column, lane)
+// tile.  One DPP step per column carries the running minimum to the next lane (wave_shr:1; lane 0, which has no
+// source, starts the next diagonal from its own key): afterwards k[15] holds, in lane l, the minimum of the
+// diagonal that ends at (column 15, lane l), and lane 63 of k[i], i < 15, that of the diagonal leaving the tile
+// at column i.  These 79 partial minima are stored for svx's merge pass (one tile covers only 16 of the up to
+// max_disp columns of a diagonal).
+constexpr int SW_PART = 80;          // partial minima stored per (row, x-block, chunk): 64 + 15, padded
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t diag_step(uint32_t run, uint32_t key) {
+    if (IS_MAX) {
+        const int sh = __builtin_amdgcn_update_dpp((int)0x80000000, (int)run, 0x138, 0xf, 0xf, false);
+        return (uint32_t)max(sh, (int)key);
+    }
+    const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)run, 0x138, 0xf, 0xf, false);
+    return min(sh, key);
+}
+
+struct RightOut { uint32_t main, dep; };   // canonical keys: lane l of main = slot l; lanes 0..14 of dep = slots 64..78
+
+template <int R, bool MASKED, bool BOTH>
+__device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, uint32_t d, int xlim_base, int dmax,
+                                                     int ilim_right, uint32_t *__restrict__ dep_lds, RightOut &ro) {
     constexpr int S = R % 5;
     constexpr bool ODD = (R & 1) != 0;
     // prefix sum along x, scaled so that the disparity fits below the cost
@@ -168,6 +189,31 @@ __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, u
         const uint32_t v = ODD ? lo - hi : hi - lo;
         key[i] = v + st.ring[S][i] + d;       // even rows: cost<<10 + d ; odd rows: -(cost<<10) + (1023 - d)
         st.ring[S][i] = v;
+    }
+    if (BOTH) {
+        uint32_t kr[SW_T];
+#pragma unroll
+        for (int i = 0; i < SW_T; ++i) kr[i] = key[i];
+        if (MASKED) {
+            // admissible for the right view: right column x-d >= 2, left column x <= cols-6, d < max_disp
+#pragma unroll
+            for (int i = 0; i < SW_T; ++i) {
+                const bool ok = (int)(ODD ? SW_DMASK - d : d) <= min(xlim_base + 3 + i, dmax) && i <= ilim_right;
+                kr[i] = ok ? kr[i] : (ODD ? (uint32_t)SW_DMASK - SW_INVALID : SW_INVALID);
+            }
+        }
+#pragma unroll
+        for (int i = 1; i < SW_T; ++i) kr[i] = diag_step<ODD>(kr[i - 1], kr[i]);
+        if (lane == 63) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4 *>(dep_lds + 4 * q) = make_uint4(kr[4 * q], kr[4 * q + 1], kr[4 * q + 2], kr[4 * q + 3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t dv = dep_lds[lane & 15];
+        __builtin_amdgcn_wave_barrier();
+        ro.main = ODD ? (uint32_t)SW_DMASK - kr[SW_T - 1] : kr[SW_T - 1];
+        ro.dep = ODD ? (uint32_t)SW_DMASK - dv : dv;
     }
     if (MASKED) {
         // disparities that would put the right window left of column 5, or beyond max_disp, never win
@@ -186,16 +232,18 @@ __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, u
 // guarantees 2 <= xb <= cols-18).
 // MIRROR: logical column c lives at memory column cols-1-c (the right-view search is the left-view search on
 // the mirrored pair with the images swapped).
-template <bool MASKED, int WORDS, bool MIRROR>
+template <bool MASKED, int WORDS, bool MIRROR, bool BOTH>
 __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int cols, int max_disp,
                                             int xb, int y_lo, int n_rows, int chunk, int lane,
-                                            uint32_t (*stage)[WORDS * SW_SLOT_WORDS], uint32_t (*best)[SW_T]) {
+                                            uint32_t (*stage)[WORDS * SW_SLOT_WORDS], uint32_t (*best)[SW_T],
+                                            uint32_t *__restrict__ dep_lds, uint32_t *__restrict__ part, long part_row_stride) {
     const int dbase = chunk << 6;
     const uint32_t d = (uint32_t)(dbase + lane);
     const uint32_t d_odd = (uint32_t)SW_DMASK - d;
     const int xq = xb - 2 - dbase - 63;             // right column held in stage word 0
     const int xlim_base = xb - 5;                   // admissible: d <= xlim_base + i
     const int dmax = max_disp - 1;
+    const int ilim_right = cols - 6 - xb;           // right view: left column xb + i must not exceed cols-6
     SweepState st;
 #pragma unroll
     for (int j = 0; j < SW_C; ++j) st.C[j] = 0;
@@ -269,9 +317,16 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
         fetch_left(min(r + 1, last), lw);                                                             \
         stash((RR + 2) % SW_SLOTS, g);                                                                \
         fetch(min(r + 3, last), g);                                                                   \
-        const uint32_t zk = sweep_row_reduce<RR, MASKED>(st, lane, (RR & 1) ? d_odd : d, xlim_base, dmax); \
-        if (r >= 4 && r < n_rows)                  /* output row y_lo + r - 4 */                      \
+        RightOut ro;                                                                                  \
+        const uint32_t zk = sweep_row_reduce<RR, MASKED, BOTH>(st, lane, (RR & 1) ? d_odd : d, xlim_base, dmax, ilim_right, dep_lds, ro); \
+        if (r >= 4 && r < n_rows) {                /* output row y_lo + r - 4 */                      \
             atomicMin(&best[r - 4][lane & 15], zk);                                                   \
+            if (BOTH) {                                                                               \
+                uint32_t *prow = part + (long)(r - 4) * part_row_stride;                              \
+                prow[lane] = ro.main;                                                                 \
+                if (lane < 16) prow[64 + lane] = ro.dep;                                              \
+            }                                                                                         \
+        }                                                                                             \
     }
     for (int r0 = 0; r0 < n_rows; r0 += 10) {
         SVX_ROW(0) SVX_ROW(1) SVX_ROW(2) SVX_ROW(3) SVX_ROW(4)
@@ -286,10 +341,12 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
 // x-block b covers output columns [xb, xb+16), xb = min(2 + 16 b, cols - 18): the last block is shifted
 // left so that it ends at column cols-3; the columns it shares with its neighbour get the same values
 // from both.  Requires cols >= 20.
-template <int WAVES_PER_SIMD, int WORDS, bool MIRROR>
+// BOTH: additionally stores the right view's partial minima (see diag_step): partial[frame][row][x-block][chunk][SW_PART].
+template <int WAVES_PER_SIMD, int WORDS, bool MIRROR, bool BOTH>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                                  int rows, int cols, int max_disp, int strip_rows, int n_xblocks,
-                                                                 float *__restrict__ disp_all, int write_border) {
+                                                                 float *__restrict__ disp_all, int write_border, uint32_t *__restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_dep[4][16];
     __shared__ __attribute__((aligned(16))) uint32_t lds_stage[4][SW_SLOTS][WORDS * SW_SLOT_WORDS];
     __shared__ uint32_t lds_best[2][SW_MAX_STRIP][SW_T];
     const int lane = threadIdx.x & 63;
@@ -318,12 +375,15 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
         const int n_chunks = (max_disp + 63) >> 6;
         for (int chunk = parity; chunk < n_chunks; chunk += 2) {
             const int dbase = chunk << 6;
-            // no disparity of this chunk is admissible for any column of the block
-            if (chunk > 0 && dbase > xb + SW_T - 1 - 5) break;
+            // no disparity of this chunk is admissible for any column of the block (left view: right column >= 5; right view: >= 2)
+            if (chunk > 0 && dbase > xb + SW_T - 1 - (BOTH ? 2 : 5)) break;
             // masking is needed when some (column, lane) pair is inadmissible
-            const bool masked = (dbase + 63 > xb - 5) || (dbase + 63 > max_disp - 1);
-            if (masked) sweep_chunk<true, WORDS, MIRROR>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
-            else sweep_chunk<false, WORDS, MIRROR>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best);
+            const bool masked = (dbase + 63 > xb - 5) || (dbase + 63 > max_disp - 1) || (BOTH && xb + SW_T - 1 > cols - 6);
+            // partial minima of this (x-block, chunk), first output row of the strip; consecutive rows are row_stride apart
+            const long row_stride = (long)n_xblocks * n_chunks * SW_PART;
+            uint32_t *part = BOTH ? partial + ((long)blockIdx.z * rows + y_lo) * row_stride + ((long)xblock * n_chunks + chunk) * SW_PART : nullptr;
+            if (masked) sweep_chunk<true, WORDS, MIRROR, BOTH>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best, lds_dep[wave], part, row_stride);
+            else sweep_chunk<false, WORDS, MIRROR, BOTH>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best, lds_dep[wave], part, row_stride);
         }
     }
     __syncthreads();
@@ -352,9 +412,37 @@ static int dense_args_ok(svx_ctx *ctx, const void *a, const void *b, const void 
     return SVX_OK;
 }
 
+// Right-view merge: the right image's disparity at (xr, y) is the minimum over the partial minima of every tile its
+// diagonal crosses.  Tile (x-block b, chunk c) holds that diagonal in slot L = xb + 15 - dbase - xr when 0 <= L <= 63
+// (it ends at the tile's last column) or in slot 142 - L when 64 <= L <= 78 (it left through lane 63).
+__global__ __launch_bounds__(256) void right_view_merge_kernel(const uint32_t *__restrict__ partial, int rows, int cols, int max_disp,
+                                                               int n_xblocks, float *__restrict__ disp_right_all) {
+    const int xr = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (xr >= cols) return;
+    float *out = disp_right_all + ((long)blockIdx.z * rows + y) * cols;
+    if (xr < 2 || xr >= cols - 2 || y < 2 || y >= rows - 2) { out[xr] = 0.0f; return; }
+    const int n_chunks = (max_disp + 63) >> 6;
+    const uint32_t *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * n_chunks * SW_PART);
+    uint32_t best = 0xffffffffu;
+    // x-blocks whose columns [xb, xb+15] meet [xr, xr + max_disp - 1]; the last block is shifted left to end at cols-3
+    const int b_lo = max(0, (xr - 2 - (SW_T - 1) + (SW_T - 1)) / SW_T - 1), b_hi = min(n_xblocks - 1, (xr + max_disp - 1 - 2) / SW_T);
+    for (int b = b_lo; b <= b_hi; ++b) {
+        const int xb = min(2 + b * SW_T, cols - 2 - SW_T);
+        if (xb + SW_T - 1 < xr) continue;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int dbase = c << 6;
+            if (c > 0 && dbase > xb + SW_T - 1 - 2) break;           // the sweep skipped this chunk
+            const int L = xb + SW_T - 1 - dbase - xr;
+            if (L < 0 || L > 78) continue;
+            best = min(best, prow[((long)b * n_chunks + c) * SW_PART + (L <= 63 ? L : 142 - L)]);
+        }
+    }
+    out[xr] = best >= SW_INVALID ? 0.0f : (float)(best & SW_DMASK);
+}
+
 template <int WORDS, bool MIRROR>
 static int launch_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
-                        float *disparity, int write_border) {
+                        float *disparity, int write_border, uint32_t *partial = nullptr) {
     // strips of SW_MAX_STRIP output rows from row 2 on: strip + 4 halo rows is a whole number of 10-row groups
     const int strip_rows = SW_MAX_STRIP;
     const int n_strips = (rows - 4 + strip_rows - 1) / strip_rows;
@@ -362,10 +450,17 @@ static int launch_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     dim3 grid(svx_cdiv(n_xblocks, 2), n_strips, n_frames);
     // Tuning knob: SVX_SWEEP_OCC=2 selects the build that may use up to 256 VGPRs (2 wavefronts per SIMD).
     static const int occ = [] { const char *e = getenv("SVX_SWEEP_OCC"); return e ? atoi(e) : 3; }();
-    if (occ == 2)
-        dense_wta5x5_sweep_kernel<2, WORDS, MIRROR><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border);
+    if (partial) {
+        if (MIRROR) return svx_fail(ctx, SVX_ERR_INVALID_ARG, "both-view sweep runs in the left view");
+        static const int occ_both = [] { const char *e = getenv("SVX_SWEEP_OCC_BOTH"); return e ? atoi(e) : 2; }();
+        if (occ_both == 3)
+            dense_wta5x5_sweep_kernel<3, WORDS, false, true><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border, partial);
+        else
+            dense_wta5x5_sweep_kernel<2, WORDS, false, true><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border, partial);
+    } else if (occ == 2)
+        dense_wta5x5_sweep_kernel<2, WORDS, MIRROR, false><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border, nullptr);
     else
-        dense_wta5x5_sweep_kernel<3, WORDS, MIRROR><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border);
+        dense_wta5x5_sweep_kernel<3, WORDS, MIRROR, false><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border, nullptr);
     SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_sweep_kernel");
     return SVX_OK;
 }
@@ -628,6 +723,44 @@ SVX_API int svx_dense_census9x7_subpixel_u8(svx_ctx *ctx, const uint8_t *left, c
     return dense_census9x7_impl(ctx, left, right, rows, cols, n_frames, max_disp, lr_threshold, 1, disparity);
 }
 
+// Left and right disparity maps from one sweep over the cost values (sweep-eligible sizes only).
+// `partial` must hold both_views_partial_words() words.
+static bool both_views_eligible(int rows, int cols, int max_disp) { return !(max_disp > SW_DMASK + 1 || cols < SW_T + 4 || rows < 5); }
+static size_t both_views_partial_words(int rows, int cols, int n_frames, int max_disp) {
+    const size_t n_xblocks = (cols - 4 + SW_T - 1) / SW_T, n_chunks = (max_disp + 63) >> 6;
+    return (size_t)n_frames * rows * n_xblocks * n_chunks * SW_PART;
+}
+static int launch_both_views(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp,
+                             float *disp_left, float *disp_right, uint32_t *partial) {
+    int rc = words == 1 ? launch_sweep<1, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disp_left, 1, partial)
+                        : launch_sweep<2, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disp_left, 1, partial);
+    if (rc) return rc;
+    const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
+    right_view_merge_kernel<<<dim3(svx_cdiv(cols, 256), rows, n_frames), 256, 0, ctx->stream>>>(partial, rows, cols, max_disp, n_xblocks, disp_right);
+    SVX_LAUNCH_CHECK(ctx, "right_view_merge_kernel");
+    return SVX_OK;
+}
+
+SVX_API int svx_dense_wta_both(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
+                               int words, int max_disp, float *disp_left, float *disp_right) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    rc = dense_args_ok(ctx, census_left, census_right, disp_left, rows, cols, n_frames, max_disp);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, disp_right != nullptr, SVX_ERR_INVALID_ARG, "svx_dense_wta_both: null pointer");
+    SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_dense_wta_both: words must be 1 or 2");
+    SVX_REQUIRE(ctx, rows <= 65535, SVX_ERR_UNSUPPORTED, "svx_dense_wta_both: too many rows per call");
+    if (!both_views_eligible(rows, cols, max_disp)) {
+        rc = launch_dense(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, words, 0);
+        if (rc) return rc;
+        return launch_dense(ctx, census_right, census_left, rows, cols, n_frames, max_disp, disp_right, 1, words, 1);
+    }
+    void *ws;
+    rc = svx_ws_reserve(ctx, both_views_partial_words(rows, cols, n_frames, max_disp) * sizeof(uint32_t), &ws);
+    if (rc) return rc;
+    return launch_both_views(ctx, census_left, census_right, rows, cols, n_frames, words, max_disp, disp_left, disp_right, (uint32_t *)ws);
+}
+
 static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
                                 int max_disp, float lr_threshold, int subpixel, float *disparity) {
     int rc = svx_enter(ctx);
@@ -636,20 +769,31 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     if (rc) return rc;
     const size_t n = (size_t)rows * cols * n_frames;
     const bool lr = lr_threshold >= 0.f;
+    // Tuning knob: SVX_LR_TWO_SWEEPS=1 computes the right view with a second (mirrored) sweep instead of from the first one's cost values.
+    static const bool two_sweeps = [] { const char *e = getenv("SVX_LR_TWO_SWEEPS"); return e && e[0] == '1'; }();
+    // the partial minima of the one-sweep path take 80 words per (row, x-block, 64-disparity chunk): beyond 4 GiB use two sweeps
+    const bool both = lr && !two_sweeps && both_views_eligible(rows, cols, max_disp) && rows <= 65535 &&
+                      both_views_partial_words(rows, cols, n_frames, max_disp) <= ((size_t)1 << 30);
+    const size_t part_words = both ? both_views_partial_words(rows, cols, n_frames, max_disp) : 0;
     void *ws;
-    rc = svx_ws_reserve(ctx, 4 * n * sizeof(uint32_t) + (lr ? n * sizeof(float) : 0), &ws);
+    rc = svx_ws_reserve(ctx, (4 * n + part_words) * sizeof(uint32_t) + (lr ? n * sizeof(float) : 0), &ws);
     if (rc) return rc;
-    uint32_t *cl = (uint32_t *)ws, *cr = cl + 2 * n;
-    float *dr = (float *)(cr + 2 * n);
+    uint32_t *cl = (uint32_t *)ws, *cr = cl + 2 * n, *partial = cr + 2 * n;
+    float *dr = (float *)(partial + part_words);
     rc = svx_census9x7_u8(ctx, left, cl, rows, cols, n_frames);
     if (rc) return rc;
     rc = svx_census9x7_u8(ctx, right, cr, rows, cols, n_frames);
     if (rc) return rc;
-    rc = launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, 2, 0);
-    if (rc) return rc;
-    if (lr) {
-        rc = launch_dense(ctx, cr, cl, rows, cols, n_frames, max_disp, dr, 1, 2, 1);
+    if (both) {
+        rc = launch_both_views(ctx, cl, cr, rows, cols, n_frames, 2, max_disp, disparity, dr, partial);
         if (rc) return rc;
+    } else {
+        rc = launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, 2, 0);
+        if (rc) return rc;
+        if (lr) rc = launch_dense(ctx, cr, cl, rows, cols, n_frames, max_disp, dr, 1, 2, 1);
+        if (rc) return rc;
+    }
+    if (lr) {
         rc = svx_lr_check(ctx, disparity, dr, rows, cols, n_frames, lr_threshold, -1.0f);
         if (rc) return rc;
     }

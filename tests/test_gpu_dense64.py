@@ -55,6 +55,23 @@ def test_dense_wta_matches_oracle(ctx, rows, cols, max_disp, words, view):
         assert np.array_equal(got[f], want), (f, np.argwhere(got[f] != want)[:5])
 
 
+@pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (12, 40, 64), (30, 150, 128), (9, 21, 5), (5, 20, 8), (16, 300, 200),
+                                                 (110, 90, 70), (8, 19, 4), (4, 30, 4), (20, 70, 1100), (40, 333, 128), (7, 1232, 128)])
+@pytest.mark.parametrize("words", [1, 2])
+def test_dense_wta_both_views_from_one_sweep(ctx, rows, cols, max_disp, words):
+    """The right view taken from the left sweep's cost values equals the oracle's right-view search (ties included)."""
+    rng = np.random.default_rng(rows * 1000 + cols + max_disp + words + 5)
+    shape = (2, rows, cols) + ((2,) if words == 2 else ())
+    cl = rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x01010101 if cols % 2 else 0xffffffff)
+    cr = np.roll(cl, -3, axis=2) ^ (rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x00010000))
+    dl, dr = ctx.dense_wta_both(dev_u32(cl), dev_u32(cr), max_disp, words=words)
+    dl, dr = dl.cpu().numpy(), dr.cpu().numpy()
+    for f in range(2):
+        wl, wr = O.dense_wta_words(cl[f], cr[f], max_disp, 0), O.dense_wta_words(cl[f], cr[f], max_disp, 1)
+        assert np.array_equal(dl[f], wl), (f, np.argwhere(dl[f] != wl)[:5])
+        assert np.array_equal(dr[f], wr), (f, np.argwhere(dr[f] != wr)[:5], dr[f][dr[f] != wr][:5], wr[dr[f] != wr][:5])
+
+
 def test_left_view_one_word_is_the_reference_search(ctx):
     """svx_dense_wta(words=1, left view) == the reference-pinned a8 restatement on its interior."""
     rng = np.random.default_rng(3)

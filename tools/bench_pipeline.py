@@ -1,0 +1,47 @@
+"""Times svx_high_perf_stereo (the full support-point / plane-prior pipeline, BASELINE configs[2]) on KITTI-size
+synthetic pairs and, beside it, the CPU oracle composition of the same pipeline.  Measurement aid (run on the GPU box)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import stereovision_amd as S  # noqa: E402
+from stereovision_amd import synth  # noqa: E402
+
+
+def main():
+    rows, cols = 375, 1242
+    ctx = S.Context(0)
+    for n_iters in (1, 2, 3):
+        p = S.StereoParameters.reference_defaults(maxDisp=70, nIters=n_iters)
+        pairs = [synth.stereo_pair(rows, cols, 64, seed)[:2] for seed in range(4)]
+        dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs]
+        out = torch.zeros((rows, cols), dtype=torch.float32, device="cuda")
+        ctx.high_perf_stereo(dev[0][0], dev[0][1], p, out)          # warm-up (workspace growth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_pts = 0
+        for l, r in dev:
+            out.zero_()
+            n_pts += len(ctx.high_perf_stereo(l, r, p, out))
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t0) * 1e3 / len(dev)
+        rec = {"pipeline": "svx_high_perf_stereo", "rows": rows, "cols": cols, "nIters": n_iters, "ms_per_frame": round(gpu_ms, 2),
+               "frames_per_s": round(1e3 / gpu_ms, 1), "points_per_frame": n_pts // len(dev)}
+        if "--cpu" in sys.argv:
+            import oracle_pipeline as OP
+            dm = np.zeros((rows, cols), np.float32)
+            t0 = time.perf_counter()
+            OP.high_perf_stereo(pairs[0][0], pairs[0][1], p, dm, S.delaunay)
+            rec["cpu_oracle_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3, 1)
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
