@@ -190,17 +190,29 @@ __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, u
         key[i] = v + st.ring[S][i] + d;       // even rows: cost<<10 + d ; odd rows: -(cost<<10) + (1023 - d)
         st.ring[S][i] = v;
     }
+    // right-view keys: the raw keys, or in masked blocks their own admissibility (right column x-d >= 2, left column
+    // x <= cols-6, d < max_disp); the diagonal chain runs after the lane reduction so that it can reuse the key registers
+    uint32_t kr[SW_T];
+    if (BOTH && MASKED) {
+#pragma unroll
+        for (int i = 0; i < SW_T; ++i) {
+            const bool ok = (int)(ODD ? SW_DMASK - d : d) <= min(xlim_base + 3 + i, dmax) && i <= ilim_right;
+            kr[i] = ok ? key[i] : (ODD ? (uint32_t)SW_DMASK - SW_INVALID : SW_INVALID);
+        }
+    }
+    if (MASKED) {
+        // disparities that would put the right window left of column 5, or beyond max_disp, never win
+#pragma unroll
+        for (int i = 0; i < SW_T; ++i) {
+            const bool ok = (int)(ODD ? SW_DMASK - d : d) <= min(xlim_base + i, dmax);
+            key[i] = ok ? key[i] : (ODD ? (uint32_t)SW_DMASK - SW_INVALID : SW_INVALID);
+        }
+    }
+    const uint32_t z = reduce16<ODD>(key, lane);
     if (BOTH) {
-        uint32_t kr[SW_T];
+        if (!MASKED) {
 #pragma unroll
-        for (int i = 0; i < SW_T; ++i) kr[i] = key[i];
-        if (MASKED) {
-            // admissible for the right view: right column x-d >= 2, left column x <= cols-6, d < max_disp
-#pragma unroll
-            for (int i = 0; i < SW_T; ++i) {
-                const bool ok = (int)(ODD ? SW_DMASK - d : d) <= min(xlim_base + 3 + i, dmax) && i <= ilim_right;
-                kr[i] = ok ? kr[i] : (ODD ? (uint32_t)SW_DMASK - SW_INVALID : SW_INVALID);
-            }
+            for (int i = 0; i < SW_T; ++i) kr[i] = key[i];
         }
 #pragma unroll
         for (int i = 1; i < SW_T; ++i) kr[i] = diag_step<ODD>(kr[i - 1], kr[i]);
@@ -215,15 +227,6 @@ __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, u
         ro.main = ODD ? (uint32_t)SW_DMASK - kr[SW_T - 1] : kr[SW_T - 1];
         ro.dep = ODD ? (uint32_t)SW_DMASK - dv : dv;
     }
-    if (MASKED) {
-        // disparities that would put the right window left of column 5, or beyond max_disp, never win
-#pragma unroll
-        for (int i = 0; i < SW_T; ++i) {
-            const bool ok = (int)(ODD ? SW_DMASK - d : d) <= min(xlim_base + i, dmax);
-            key[i] = ok ? key[i] : (ODD ? (uint32_t)SW_DMASK - SW_INVALID : SW_INVALID);
-        }
-    }
-    const uint32_t z = reduce16<ODD>(key, lane);
     return ODD ? (uint32_t)SW_DMASK - z : z;    // canonical key: cost << 10 | d
 }
 
@@ -750,7 +753,8 @@ SVX_API int svx_dense_wta_both(svx_ctx *ctx, const uint32_t *census_left, const 
     SVX_REQUIRE(ctx, disp_right != nullptr, SVX_ERR_INVALID_ARG, "svx_dense_wta_both: null pointer");
     SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_dense_wta_both: words must be 1 or 2");
     SVX_REQUIRE(ctx, rows <= 65535, SVX_ERR_UNSUPPORTED, "svx_dense_wta_both: too many rows per call");
-    if (!both_views_eligible(rows, cols, max_disp)) {
+    // sizes the sweep kernel does not cover, or whose partial minima would exceed 4 GiB: one search per view
+    if (!both_views_eligible(rows, cols, max_disp) || both_views_partial_words(rows, cols, n_frames, max_disp) > ((size_t)1 << 30)) {
         rc = launch_dense(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, words, 0);
         if (rc) return rc;
         return launch_dense(ctx, census_right, census_left, rows, cols, n_frames, max_disp, disp_right, 1, words, 1);
