@@ -216,6 +216,7 @@ __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, u
         }
 #pragma unroll
         for (int i = 1; i < SW_T; ++i) kr[i] = diag_step<ODD>(kr[i - 1], kr[i]);
+        // the 15 minima that left through lane 63 are gathered into lanes 0..14 of one register through LDS
         if (lane == 63) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -224,7 +225,7 @@ __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, u
         __builtin_amdgcn_wave_barrier();
         const uint32_t dv = dep_lds[lane & 15];
         __builtin_amdgcn_wave_barrier();
-        ro.main = ODD ? (uint32_t)SW_DMASK - kr[SW_T - 1] : kr[SW_T - 1];
+        ro.main = ODD ? (uint32_t)SW_DMASK - kr[SW_T - 1] : kr[SW_T - 1];     // canonical keys: cost << 10 | d
         ro.dep = ODD ? (uint32_t)SW_DMASK - dv : dv;
     }
     return ODD ? (uint32_t)SW_DMASK - z : z;    // canonical key: cost << 10 | d
@@ -349,9 +350,9 @@ template <int WAVES_PER_SIMD, int WORDS, bool MIRROR, bool BOTH>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                                  int rows, int cols, int max_disp, int strip_rows, int n_xblocks,
                                                                  float *__restrict__ disp_all, int write_border, uint32_t *__restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_dep[4][16];
     __shared__ __attribute__((aligned(16))) uint32_t lds_stage[4][SW_SLOTS][WORDS * SW_SLOT_WORDS];
     __shared__ uint32_t lds_best[2][SW_MAX_STRIP][SW_T];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_dep[4][16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave >> 1, parity = wave & 1;
@@ -417,7 +418,29 @@ static int dense_args_ok(svx_ctx *ctx, const void *a, const void *b, const void 
 
 // Right-view merge: the right image's disparity at (xr, y) is the minimum over the partial minima of every tile its
 // diagonal crosses.  Tile (x-block b, chunk c) holds that diagonal in slot L = xb + 15 - dbase - xr when 0 <= L <= 63
-// (it ends at the tile's last column) or in slot 142 - L when 64 <= L <= 78 (it left through lane 63).
+// (it ends at the tile's last column) or in slot 142 - L when 64 <= L <= 78 (it left through lane 63).  The left
+// columns xr + dbase .. xr + dbase + 63 of a chunk lie in five consecutive x-blocks at most.
+__device__ __forceinline__ float right_disparity(const uint32_t *__restrict__ prow, int xr, int cols, int n_xblocks, int n_chunks) {
+    uint32_t best = 0xffffffffu;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int dbase = c << 6;
+        const int b0 = (xr + dbase - 2) >> 4;                       // block of left column xr + dbase (floor; may be -1)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int b = b0 + k;
+            const int bc = min(max(b, 0), n_xblocks - 1);
+            const int xb = min(2 + bc * SW_T, cols - 2 - SW_T);     // the last block is shifted left to end at cols-3
+            const int L = xb + SW_T - 1 - dbase - xr;
+            // the sweep skips chunks none of whose disparities is admissible for the block
+            const bool ok = b == bc && L >= 0 && L <= 78 && !(c > 0 && dbase > xb + SW_T - 1 - 2);
+            const int slot = L <= 63 ? L : 142 - L;
+            const uint32_t v = prow[((long)bc * n_chunks + c) * SW_PART + min(max(slot, 0), SW_PART - 1)];
+            best = min(best, ok ? v : 0xffffffffu);
+        }
+    }
+    return best >= SW_INVALID ? 0.0f : (float)(best & SW_DMASK);
+}
+
 __global__ __launch_bounds__(256) void right_view_merge_kernel(const uint32_t *__restrict__ partial, int rows, int cols, int max_disp,
                                                                int n_xblocks, float *__restrict__ disp_right_all) {
     const int xr = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -426,21 +449,21 @@ __global__ __launch_bounds__(256) void right_view_merge_kernel(const uint32_t *_
     if (xr < 2 || xr >= cols - 2 || y < 2 || y >= rows - 2) { out[xr] = 0.0f; return; }
     const int n_chunks = (max_disp + 63) >> 6;
     const uint32_t *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * n_chunks * SW_PART);
-    uint32_t best = 0xffffffffu;
-    // x-blocks whose columns [xb, xb+15] meet [xr, xr + max_disp - 1]; the last block is shifted left to end at cols-3
-    const int b_lo = max(0, (xr - 2 - (SW_T - 1) + (SW_T - 1)) / SW_T - 1), b_hi = min(n_xblocks - 1, (xr + max_disp - 1 - 2) / SW_T);
-    for (int b = b_lo; b <= b_hi; ++b) {
-        const int xb = min(2 + b * SW_T, cols - 2 - SW_T);
-        if (xb + SW_T - 1 < xr) continue;
-        for (int c = 0; c < n_chunks; ++c) {
-            const int dbase = c << 6;
-            if (c > 0 && dbase > xb + SW_T - 1 - 2) break;           // the sweep skipped this chunk
-            const int L = xb + SW_T - 1 - dbase - xr;
-            if (L < 0 || L > 78) continue;
-            best = min(best, prow[((long)b * n_chunks + c) * SW_PART + (L <= 63 ? L : 142 - L)]);
-        }
-    }
-    out[xr] = best >= SW_INVALID ? 0.0f : (float)(best & SW_DMASK);
+    out[xr] = right_disparity(prow, xr, cols, n_xblocks, n_chunks);
+}
+
+// Left-right check straight from the partial minima: lr_check_kernel's rule with the right disparity merged on demand.
+__global__ __launch_bounds__(256) void lr_check_partial_kernel(float *__restrict__ dl_all, const uint32_t *__restrict__ partial, int rows, int cols,
+                                                               int max_disp, int n_xblocks, float threshold, float invalid) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
+    float *dl = dl_all + ((long)blockIdx.z * rows + y) * cols;
+    const float d1 = dl[x];
+    const int xr = x - (int)d1;
+    if (xr < 2) { dl[x] = invalid; return; }
+    const int n_chunks = (max_disp + 63) >> 6;
+    const uint32_t *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * n_chunks * SW_PART);
+    if (fabsf(right_disparity(prow, xr, cols, n_xblocks, n_chunks) - d1) > threshold) dl[x] = invalid;
 }
 
 template <int WORDS, bool MIRROR>
@@ -780,7 +803,7 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
                       both_views_partial_words(rows, cols, n_frames, max_disp) <= ((size_t)1 << 30);
     const size_t part_words = both ? both_views_partial_words(rows, cols, n_frames, max_disp) : 0;
     void *ws;
-    rc = svx_ws_reserve(ctx, (4 * n + part_words) * sizeof(uint32_t) + (lr ? n * sizeof(float) : 0), &ws);
+    rc = svx_ws_reserve(ctx, (4 * n + part_words) * sizeof(uint32_t) + (lr && !both ? n * sizeof(float) : 0), &ws);
     if (rc) return rc;
     uint32_t *cl = (uint32_t *)ws, *cr = cl + 2 * n, *partial = cr + 2 * n;
     float *dr = (float *)(partial + part_words);
@@ -789,15 +812,20 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     rc = svx_census9x7_u8(ctx, right, cr, rows, cols, n_frames);
     if (rc) return rc;
     if (both) {
-        rc = launch_both_views(ctx, cl, cr, rows, cols, n_frames, 2, max_disp, disparity, dr, partial);
+        // one sweep; the check reads the right view's partial minima directly (no right disparity map is formed)
+        rc = launch_sweep<2, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, partial);
         if (rc) return rc;
+        const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
+        lr_check_partial_kernel<<<dim3(svx_cdiv(cols, 256), rows, n_frames), 256, 0, ctx->stream>>>(disparity, partial, rows, cols, max_disp,
+                                                                                                      n_xblocks, lr_threshold, -1.0f);
+        SVX_LAUNCH_CHECK(ctx, "lr_check_partial_kernel");
     } else {
         rc = launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, 2, 0);
         if (rc) return rc;
         if (lr) rc = launch_dense(ctx, cr, cl, rows, cols, n_frames, max_disp, dr, 1, 2, 1);
         if (rc) return rc;
     }
-    if (lr) {
+    if (lr && !both) {
         rc = svx_lr_check(ctx, disparity, dr, rows, cols, n_frames, lr_threshold, -1.0f);
         if (rc) return rc;
     }
