@@ -3,9 +3,10 @@
 
 One step = one pass of the fused hot path over one batch of synthetic rectified frames that is already
 resident in HBM.  Variants (--variant):
-  9x7lr  (default) u8 -> 9x7 census (64-bit) on both images -> 5x5-aggregated Hamming WTA in the left
-         view -> the same in the right view -> left-right check: the "dense census 9x7 + Hamming/WTA +
-         L-R check" configuration.
+  9x7lr  (default) u8 -> 9x7 census (64-bit) on both images -> 5x5-aggregated Hamming WTA in both views
+         from ONE sweep over the cost values (the cost of left column x at disparity d is the cost of
+         right pixel x-d at d) -> left-right check: the "dense census 9x7 + Hamming/WTA + L-R check"
+         configuration.
   9x7    the same without the right view and the check.
   5x5    u8 -> 5x5 census (24-bit, the reference's transform) -> WTA, the reference-pinned variant.
 Workload: KITTI-size 1242x375 frames cropped to the multiple-of-16 size 1232x368 the reference works
@@ -185,7 +186,9 @@ def main():
         n_k = max(5, min(args.steps, 20))
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        timed = S.dominant_kernel_timer(ctx, left, right, D, disp, words)
+        two_sweeps = os.environ.get("SVX_LR_TWO_SWEEPS", "0") == "1"
+        both_views = lr and not two_sweeps
+        timed = S.dominant_kernel_timer(ctx, left, right, D, disp, words, both_views=both_views)
         timed()                                   # warm
         e0.record(stream)
         for _ in range(n_k):
@@ -202,7 +205,7 @@ def main():
         achieved = valu_ops / (k_ms * 1e-3) / 1e12
         traffic = None   # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_w%d.json" % words)))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_w%d%s.json" % (words, "_both" if both_views else ""))))
             if tj["kernel"] == S.DOMINANT_KERNEL and tj["words"] == words and F == 64 and D == 128:
                 traffic = (tj["fetch_size_kb"] + tj["write_size_kb"]) * 1024.0
         except Exception:
@@ -216,7 +219,8 @@ def main():
             "frac": round(achieved / VALU_PEAK_TLOPS, 4),
             "traffic": traffic,
             "kernel_ms": round(k_ms, 4),
-            "launches_per_step": 2 if lr else 1,
+            "kernel_variant": "both views from one sweep (left map + right view's partial minima)" if both_views else "left view",
+            "launches_per_step": 2 if (lr and not both_views) else 1,
             "algorithmic_ops_per_launch": valu_ops,
             "measured_xor_bcnt_peak": None if measured_peak is None else round(measured_peak, 2),
             "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,
@@ -224,8 +228,21 @@ def main():
                     "peak_GBs": HBM_PEAK_GBS,
                     "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "note": "not an MFMA or HBM bound path: priced against the VALU popcount floor "
-                    "(2 lane-instr per pix*disp per 32-bit descriptor word, aggregation and argmin not counted)",
+                    "(2 lane-instr per pix*disp per 32-bit descriptor word, aggregation and argmin not counted; "
+                    "the both-views kernel is priced on ONE cost volume although it serves two searches)",
         }
+        if both_views:
+            # the single-view sweep beside it (what --variant 9x7 runs, and SVX_LR_TWO_SWEEPS=1 runs twice)
+            t1 = S.dominant_kernel_timer(ctx, left, right, D, disp, words)
+            t1()
+            e0.record(stream)
+            for _ in range(n_k):
+                t1()
+            e1.record(stream)
+            e1.synchronize()
+            k1_ms = e0.elapsed_time(e1) / n_k
+            roofline["left_view_sweep"] = {"kernel_ms": round(k1_ms, 4), "achieved": round(valu_ops / (k1_ms * 1e-3) / 1e12, 3),
+                                           "frac": round(valu_ops / (k1_ms * 1e-3) / 1e12 / VALU_PEAK_TLOPS, 4)}
 
         # ---- CPU baseline (oracle port, 1 thread) + parity spot check on the same frame ----
         cpu = None

@@ -367,6 +367,11 @@ int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_t *right
  * v_add_u32, v_add3_u32, v_min_u32, DPP v_add_u32, v_pk_add_u16,
  * v_mad_u32_u24 and v_lshl_add_u32.  Synchronous. */
 int svx_probe_valu_rate(svx_ctx *ctx, int mode, int waves_per_simd, int iters, double *lane_ops_per_s);
+/* Launches exactly the kernel the left-right entry points spend most of their time in (one sweep over the
+ * cost values that writes the left map and leaves the right view's partial minima in the workspace), so
+ * that a benchmark can bracket it with stream events.  Asynchronous. */
+int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                               int n_frames, int words, int max_disp, float *disp_left);
 
 #ifdef __cplusplus
 }

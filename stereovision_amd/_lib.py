@@ -65,6 +65,7 @@ EXPORTS = {
     "svx_dense_point_cloud": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_double, _vp, _vp, _i, _vp]),
     "svx_high_perf_stereo": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
+    "svx_probe_both_views_sweep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 
 
@@ -592,11 +593,15 @@ def delaunay(pts_xy):
 DOMINANT_KERNEL = "dense_wta5x5_sweep_kernel"
 
 
-def dominant_kernel_timer(ctx, left, right, max_disp, disp, words=1):
-    """Returns a zero-argument callable that launches exactly the dominant kernel of the hot path
-    (the dense WTA, left view) once, on inputs prepared here, so that it can be bracketed by stream events."""
+def dominant_kernel_timer(ctx, left, right, max_disp, disp, words=1, both_views=False):
+    """Returns a zero-argument callable that launches exactly the dominant kernel of the hot path once, on inputs
+    prepared here, so that it can be bracketed by stream events: the dense sweep in the left view, or with
+    both_views the sweep that also leaves the right view's partial minima (what the left-right entry points run)."""
     if words == 2:
         cl, cr = ctx.census9x7(left), ctx.census9x7(right)
+        if both_views:
+            f, r, c = _frames(left)
+            return lambda: ctx._call("svx_probe_both_views_sweep", _dptr(cl), _dptr(cr), r, c, f, 2, int(max_disp), _dptr(disp))
         return lambda: ctx.dense_wta(cl, cr, max_disp, VIEW_LEFT, 2, out=disp)
     cl = ctx.census5x5(left, CENSUS_SSE24 | CENSUS_ZERO_REST)
     cr = ctx.census5x5(right, CENSUS_SSE24 | CENSUS_ZERO_REST)

@@ -788,6 +788,25 @@ SVX_API int svx_dense_wta_both(svx_ctx *ctx, const uint32_t *census_left, const 
     return launch_both_views(ctx, census_left, census_right, rows, cols, n_frames, words, max_disp, disp_left, disp_right, (uint32_t *)ws);
 }
 
+// Measurement aid: launches exactly the both-views sweep kernel (left map + the right view's partial minima in the
+// workspace), the kernel the left-right entry points spend most of their time in, so that it can be timed alone.
+SVX_API int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                                       int n_frames, int words, int max_disp, float *disp_left) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    rc = dense_args_ok(ctx, census_left, census_right, disp_left, rows, cols, n_frames, max_disp);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_probe_both_views_sweep: words must be 1 or 2");
+    SVX_REQUIRE(ctx, both_views_eligible(rows, cols, max_disp) && rows <= 65535 &&
+                     both_views_partial_words(rows, cols, n_frames, max_disp) <= ((size_t)1 << 30),
+                SVX_ERR_UNSUPPORTED, "svx_probe_both_views_sweep: size not covered by the both-views sweep");
+    void *ws;
+    rc = svx_ws_reserve(ctx, both_views_partial_words(rows, cols, n_frames, max_disp) * sizeof(uint32_t), &ws);
+    if (rc) return rc;
+    return words == 1 ? launch_sweep<1, false>(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, (uint32_t *)ws)
+                      : launch_sweep<2, false>(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, (uint32_t *)ws);
+}
+
 static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
                                 int max_disp, float lr_threshold, int subpixel, float *disparity) {
     int rc = svx_enter(ctx);
