@@ -358,6 +358,14 @@ typedef struct svx_stereo_parameters {
 int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols,
                          const svx_stereo_parameters *parameters, float *disparity_map,
                          int32_t *points_xy_host, int capacity, int *n_points);
+/* Wall-clock milliseconds of the stages of the context's last svx_high_perf_stereo call, in the spirit of the
+ * per-stage table the reference's demo prints (highPerfStereo/highPerfStereo.cpp:97-99, :591-595):
+ * [0] crop + equalisation, [1] gradient + high-gradient set, [2] row alterations + exFAST (both images),
+ * [3] census (both images), [4] sparse matching, [5] support points to the device, [6] mesh + plane prior (all
+ * iterations), [7] cost evaluation + refinement (all iterations), [8] support resampling (all iterations),
+ * [9] final vertex pass + results to the caller.  Up to n values are written. */
+#define SVX_PIPELINE_STAGES 10
+int svx_pipeline_stage_times(const svx_ctx *ctx, double *ms, int n);
 
 /* ---- measurement aid (no counterpart in the reference) ---------------------
  * Sustained issue rate, in lane-instructions per second, of the VALU pairs the

@@ -64,6 +64,7 @@ EXPORTS = {
     "svx_point_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_dense_point_cloud": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_double, _vp, _vp, _i, _vp]),
     "svx_high_perf_stereo": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
+    "svx_pipeline_stage_times": (_i, [_vp, _vp, _i]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
     "svx_probe_both_views_sweep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
@@ -552,6 +553,15 @@ class Context:
         self._call("svx_high_perf_stereo", _dptr(left), _dptr(right), rows, cols, C.byref(params), _dptr(disparity_map),
                    pts.ctypes.data_as(_vp), cap, C.byref(n))
         return pts[:min(n.value, cap)].copy()
+
+    PIPELINE_STAGES = ("crop+equalise", "gradient+points", "alter+exFAST", "census", "sparse match", "support upload",
+                       "mesh+prior", "cost+refine", "resampling", "finalise")
+
+    def pipeline_stage_times(self):
+        """Milliseconds per stage of the last high_perf_stereo call: dict stage name -> ms."""
+        ms = (C.c_double * len(self.PIPELINE_STAGES))()
+        self._call("svx_pipeline_stage_times", ms, len(self.PIPELINE_STAGES))
+        return dict(zip(self.PIPELINE_STAGES, [round(v, 3) for v in ms]))
 
     # ---- point cloud ----
     def point_cloud(self, pts_xy, disparity_map, q, roi=(0, 0), bgr=None, max_range=8000.0, capacity=None):

@@ -15,6 +15,7 @@ struct svx_ctx {
     void *pinned;         // pinned host staging buffer, grown on demand
     size_t pinned_bytes;
     char err[256];
+    double stage_ms[SVX_PIPELINE_STAGES];   // wall-clock per stage of the last svx_high_perf_stereo call
 };
 
 #define SVX_API extern "C" __attribute__((visibility("default")))

@@ -4,6 +4,7 @@
 // as the reference's host code does.
 #include "svx_common.hpp"
 #include <algorithm>
+#include <chrono>
 #include <unordered_set>
 #include <vector>
 
@@ -34,6 +35,22 @@ struct Arena {
         T *p = reinterpret_cast<T *>(base + used);
         used += n * sizeof(T);
         return p;
+    }
+};
+
+// Stage clock: the pipeline is host-synchronous at its list hand-overs anyway; a mark waits for the stream and books
+// the time since the previous mark to one stage.
+struct StageClock {
+    svx_ctx *ctx;
+    std::chrono::steady_clock::time_point t;
+    explicit StageClock(svx_ctx *c) : ctx(c), t(std::chrono::steady_clock::now()) {
+        for (int i = 0; i < SVX_PIPELINE_STAGES; ++i) c->stage_ms[i] = 0.0;
+    }
+    void mark(int stage) {
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        ctx->stage_ms[stage] += std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
     }
 };
 
@@ -101,6 +118,7 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     a.base = (char *)guard.p;
     layout(a);
 
+    StageClock clk(ctx);
     // crop to multiples of 16, equalise, gradient, high-gradient point set (.cpp:245-280)
     SVX_TRY(svx_crop16(ctx, left, rows, cols, 1, L));
     SVX_TRY(svx_crop16(ctx, right, rows, cols, 1, Rr));
@@ -108,12 +126,14 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         SVX_TRY(svx_equalize_hist(ctx, L, L, R, Cc, 1));
         SVX_TRY(svx_equalize_hist(ctx, Rr, Rr, R, Cc, 1));
     }
+    clk.mark(0);
     SVX_TRY(svx_laplacian_abs(ctx, L, grad, R, Cc, 1, prm->kernelSize, (double)prm->scale, (double)prm->delta));
     int off[2] = {0, 0};
     SVX_TRY(svx_high_gradient_points(ctx, grad, R, Cc, 1, prm->gradThreshold, pts, (int)n, off));
     const int n_hg = off[1];
     // .cpp:289-292: the blur kernel size is `(int)applyBlur` = 1 (.cpp:207), i.e. the blur is the identity
 
+    clk.mark(1);
     // altered copies for the detector only (.cpp:296-335)
     SVX_HIP(ctx, hipMemcpyAsync(La, L, n, hipMemcpyDeviceToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(Ra, Rr, n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -127,9 +147,11 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     SVX_TRY(svx_exfast_detect(ctx, La, R, Cc, 1, prm->minThreshold, (float)prm->adaptivity, SVX_EXFAST_NONMAX, kpl, respl, (int)n, offl));
     SVX_TRY(svx_exfast_detect(ctx, Ra, R, Cc, 1, prm->minThreshold, (float)prm->adaptivity, 0, kpr, respr, (int)n, offr));
     const int nl = offl[1], nr = offr[1];
+    clk.mark(2);
     SVX_TRY(svx_census5x5_u8(ctx, L, cL, R, Cc, 1, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST));
     SVX_TRY(svx_census5x5_u8(ctx, Rr, cR, R, Cc, 1, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST));
 
+    clk.mark(3);
     // sparse matching of the key points (.cpp:354-355, :390)
     std::vector<int32_t> hl(2 * (size_t)nl), hr(2 * (size_t)nr);
     if (nl) SVX_HIP(ctx, hipMemcpyAsync(hl.data(), kpl, hl.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -143,6 +165,7 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     SVX_TRY(svx_sparse_match(ctx, cL, cR, R, Cc, fl.data(), nl, fr.data(), nr, prm->maxDisp, 1.0f, (float)prm->uniqueness, prm->leftRightStep,
                              ml.data(), mr.data(), mc.data(), &n_rec));
 
+    clk.mark(4);
     // support points of the mesh, in insertion order, repeated positions dropped (.cpp:434-445)
     std::vector<int32_t> sup;                 // x,y pairs
     std::vector<float> sup_d;
@@ -182,16 +205,19 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     SVX_HIP(ctx, hipMemcpy2DAsync(final_disp, (size_t)Cc * 4, disparity_map, (size_t)cols * 4, (size_t)Cc * 4, R, hipMemcpyDeviceToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemsetAsync(final_costs, 25, n, ctx->stream));
 
+    clk.mark(5);
     for (int iter = 1; iter <= prm->nIters; ++iter) {                                                   // .cpp:451
         // plane table and interpolation of the prior over the whole frame (.cpp:454-466, :532-554)
         if (prm->recordFullDisp) {
             int n_tri = 0;
             SVX_TRY(svx_mesh_plane_prior(ctx, sup.data(), (int)(sup.size() / 2), disparities, R, Cc, disparities, &n_tri));
         }
+        clk.mark(6);
         SVX_HIP(ctx, hipMemsetAsync(costs, t_high & 0xff, n, ctx->stream));                             // .cpp:573
         SVX_TRY(svx_cost_eval(ctx, cL, cR, R, Cc, pts, n_hg, disparities, costs));                      // .cpp:574
         SVX_TRY(svx_refine(ctx, pts, n_hg, disparities, costs, R, Cc, t_low, t_high, occ, final_disp, final_costs,
                            conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c));                       // .cpp:575-576
+        clk.mark(7);
         if (iter != prm->nIters) {                                                                      // .cpp:616-621
             const int gw = Cc / (int)occ + 1, gh = R / (int)occ + 1;
             const size_t nc = (size_t)gw * gh;
@@ -205,6 +231,7 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
             for (size_t s = 0; s < 2 * nc; ++s)
                 if (hv[s]) insert_point(hxy[2 * s], hxy[2 * s + 1]);
             occ = std::max(1u, occ / 2);
+            clk.mark(8);
         }
     }
 
@@ -233,5 +260,12 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         points_xy_host[2 * (size_t)(n_hg + i)] = sup[2 * i];
         points_xy_host[2 * (size_t)(n_hg + i) + 1] = sup[2 * i + 1];
     }
+    clk.mark(9);
+    return SVX_OK;
+}
+
+SVX_API int svx_pipeline_stage_times(const svx_ctx *ctx, double *ms, int n) {
+    if (!ctx || !ms || n < 0) return SVX_ERR_INVALID_ARG;
+    for (int i = 0; i < n && i < SVX_PIPELINE_STAGES; ++i) ms[i] = ctx->stage_ms[i];
     return SVX_OK;
 }

@@ -32,8 +32,9 @@ def main():
             n_pts += len(ctx.high_perf_stereo(l, r, p, out))
         torch.cuda.synchronize()
         gpu_ms = (time.perf_counter() - t0) * 1e3 / len(dev)
+        stages = ctx.pipeline_stage_times()
         rec = {"pipeline": "svx_high_perf_stereo", "rows": rows, "cols": cols, "nIters": n_iters, "ms_per_frame": round(gpu_ms, 2),
-               "frames_per_s": round(1e3 / gpu_ms, 1), "points_per_frame": n_pts // len(dev)}
+               "frames_per_s": round(1e3 / gpu_ms, 1), "points_per_frame": n_pts // len(dev), "stage_ms_last_frame": stages}
         if "--cpu" in sys.argv:
             import oracle_pipeline as OP
             dm = np.zeros((rows, cols), np.float32)
