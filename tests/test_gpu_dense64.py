@@ -174,3 +174,32 @@ def test_subpixel_4k_512_disparities(ctx):
     assert np.array_equal(integer.cpu().numpy()[y0:y1], band[y0:y1])
     fused = ctx.dense_census9x7_subpixel(dl, dr, D, lr_threshold=-1.0).cpu().numpy()
     assert np.array_equal(fused, refined)
+
+
+@pytest.mark.parametrize("frames,rows,cols,D,band", [(2, 1072, 1920, 256, (500, 503)), (1, 2160, 3840, 512, (1000, 1002))])
+def test_left_right_full_size_configs(ctx, frames, rows, cols, D, band):
+    """configs[3] (1920x1080 cropped to /16, D=256) and configs[4] (3840x2160, D=512) through the fused left-right entry
+    point: against the oracle on a band of rows of every frame; the pixels the check rejects are exactly those where the two
+    separately computed views disagree (whole frame, device results of the one-view searches)."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    ls, rs = synth.stereo_batch(rows, cols, D, frames, seed0=40 + frames)
+    dl, dr = dev(ls), dev(rs)
+    got = ctx.dense_census9x7_lr(dl, dr, D, lr_threshold=1.0).cpu().numpy()
+    cl, cr = ctx.census9x7(dl), ctx.census9x7(dr)
+    left_map = ctx.dense_wta(cl, cr, D, S.VIEW_LEFT, 2)
+    right_map = ctx.dense_wta(cl, cr, D, S.VIEW_RIGHT, 2)
+    y0, y1 = band
+    for f in range(frames):
+        hcl, hcr = O.census9x7(ls[f]), O.census9x7(rs[f])
+        wl = O.dense_wta_words(hcl, hcr, D, 0, y0, y1)
+        wr = O.dense_wta_words(hcl, hcr, D, 1, y0, y1)
+        assert np.array_equal(left_map[f].cpu().numpy()[y0:y1], wl[y0:y1])
+        assert np.array_equal(right_map[f].cpu().numpy()[y0:y1], wr[y0:y1])
+        want_band = O.lr_check(wl, wr, 1.0, -1.0)
+        assert np.array_equal(got[f][y0:y1], want_band[y0:y1])
+    # whole frames: the one-sweep path equals the check applied to the two one-view searches
+    two = ctx.lr_check(left_map.clone(), right_map, 1.0).cpu().numpy()
+    assert np.array_equal(got, two)
+    both_l, both_r = ctx.dense_wta_both(cl, cr, D, words=2)
+    assert torch.equal(both_l, left_map) and torch.equal(both_r, right_map)
