@@ -5,11 +5,13 @@
 // triangle's circumcircle.  Where four or more points are cocircular the diagonal is a free choice and
 // may differ from Fade2D's.
 //
-// Construction: points sorted by (x, y) are added one at a time; each new point lies outside the hull
-// built so far and is joined to every hull edge it sees, then the new edges are legalised by flips.
+// Construction: points are added one at a time in order of their distance from a central input point; each
+// new point lies outside the hull built so far and is joined to every hull edge it sees (found from a table
+// of hull vertices by direction), then the new edges are legalised by flips.
 // All predicates are exact (64/128-bit integers; coordinates must fit in 24 bits).
 #include "svx_common.hpp"
 #include <algorithm>
+#include <cmath>
 #include <numeric>
 #include <vector>
 
@@ -30,27 +32,85 @@ inline int in_circle(const Pt &a, const Pt &b, const Pt &c, const Pt &d) {
     return det > 0 ? 1 : (det < 0 ? -1 : 0);
 }
 
+// The same test in 64-bit arithmetic, exact while every coordinate difference is below 2^15 in magnitude (squared
+// lengths < 2^31, cross products < 2^31, three products of < 2^62 cannot overflow once their signs are mixed; the
+// caller enables it for |coordinates| <= 2^13, where the sum stays below 2^59).
+inline int in_circle_small(const Pt &a, const Pt &b, const Pt &c, const Pt &d) {
+    const i64 ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+    const i64 a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+    const i64 det = a2 * (bx * cy - by * cx) - b2 * (ax * cy - ay * cx) + c2 * (ax * by - ay * bx);
+    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+}
+
 struct Tri { int v[3]; int n[3]; };      // n[i]: triangle across the edge opposite v[i], -1 on the hull
 
 class Delaunay {
 public:
     std::vector<Pt> p;                   // unique points in (x, y) order
     std::vector<Tri> t;
+    bool small_ = false;                 // every |coordinate| <= 2^13: the 64-bit circle test is exact
 
     void build() {
         const int n = (int)p.size();
-        next_.assign(n, -1); prev_.assign(n, -1); hull_tri_.assign(n, -1);
+        small_ = true;
+        for (const Pt &q : p) small_ = small_ && q.x >= -8192 && q.x <= 8192 && q.y >= -8192 && q.y <= 8192;
+        t.reserve(2 * (size_t)n);
+        next_.assign(n, -1); prev_.assign(n, -1); hull_tri_.assign(n, -1); on_hull_.assign(n, 0);
         if (n < 3) return;
+        // Radial order around the input point nearest the middle of the bounding box (exact integer distances): the
+        // points before any point q lie in the closed disc through q, so q lies outside their hull, and the hull grows
+        // as a blob instead of a sliver, which keeps the number of flips per point small.
+        i64 x0 = p[0].x, x1 = p[0].x, y0 = p[0].y, y1 = p[0].y;
+        for (const Pt &q : p) { x0 = std::min(x0, q.x); x1 = std::max(x1, q.x); y0 = std::min(y0, q.y); y1 = std::max(y1, q.y); }
+        int c = 0;
+        i64 best = -1;
+        for (int i = 0; i < n; ++i) {
+            const i64 dx = 2 * p[i].x - (x0 + x1), dy = 2 * p[i].y - (y0 + y1), d2 = dx * dx + dy * dy;
+            if (best < 0 || d2 < best) { best = d2; c = i; }
+        }
+        centre_ = p[c];
+        const Pt ctr = centre_;
+        std::sort(p.begin(), p.end(), [ctr](const Pt &a, const Pt &b) {
+            const i64 da = (a.x - ctr.x) * (a.x - ctr.x) + (a.y - ctr.y) * (a.y - ctr.y);
+            const i64 db = (b.x - ctr.x) * (b.x - ctr.x) + (b.y - ctr.y) * (b.y - ctr.y);
+            return da != db ? da < db : (a.x != b.x ? a.x < b.x : a.y < b.y);
+        });
         int k = 2;                       // p[0..k) is the leading collinear run
         while (k < n && orient(p[0], p[1], p[k]) == 0) ++k;
         if (k == n) return;              // every point on one line: no triangle
+        // the fan below needs the run in order along its line
+        std::sort(p.begin(), p.begin() + k, [](const Pt &a, const Pt &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
         seed(k);
-        for (int i = k + 1; i < n; ++i) add_outside(i, i - 1);
+        hash_.assign((size_t)1 << hash_bits(n), -1);
+        for (int v = 0, u = k; v <= k; ++v, u = next_[u]) { on_hull_[u] = 1; hash_[hash_key(p[u])] = u; }
+        for (int i = k + 1; i < n; ++i) add_outside(i, hull_hint(p[i]));
     }
 
 private:
     std::vector<int> next_, prev_, hull_tri_;    // counter-clockwise hull; hull_tri_[u] owns edge u -> next_[u]
     std::vector<std::pair<int, int>> stack_;
+    std::vector<char> on_hull_;
+    std::vector<int> hash_;                      // hull vertices by direction from the centre: a starting hint only
+    Pt centre_;
+
+    static int hash_bits(int n) { int b = 4; while (((size_t)1 << (2 * b)) < (size_t)n) ++b; return b; }   // ~ sqrt(n) buckets
+    size_t hash_key(const Pt &q) const {
+        const double dx = (double)(q.x - centre_.x), dy = (double)(q.y - centre_.y);
+        const double s = fabs(dx) + fabs(dy);
+        if (s == 0.0) return 0;
+        const double r = dx / s, a = (dy > 0.0 ? 3.0 - r : 1.0 + r) * 0.25;                  // monotone in the angle, in [0, 1]
+        const size_t m = hash_.size();
+        return std::min(m - 1, (size_t)(a * (double)m));
+    }
+    // A vertex still on the hull in (or after) the direction of q; any hull vertex is a correct hint, a near one a fast one.
+    int hull_hint(const Pt &q) const {
+        const size_t m = hash_.size(), k0 = hash_key(q);
+        for (size_t j = 0; j < m; ++j) {
+            const int v = hash_[(k0 + j) & (m - 1)];
+            if (v >= 0 && on_hull_[v]) return v;
+        }
+        return 0;      // not reached: the hull always has vertices in the table
+    }
 
     int new_tri(int a, int b, int c) {
         Tri x; x.v[0] = a; x.v[1] = b; x.v[2] = c; x.n[0] = x.n[1] = x.n[2] = -1;
@@ -90,18 +150,23 @@ private:
 
     // Joins point q (outside the hull) to all hull edges it sees; `hint` is a hull vertex next to one.
     void add_outside(int q, int hint) {
-        int first = -1;                   // first vertex (in hull order) of the visible chain
+        int first = -1;                   // a vertex whose hull edge q sees; the chain is then extended backwards
         if (sees(hint, q)) first = hint;
-        else if (sees(prev_[hint], q)) first = prev_[hint];
-        else {                            // not expected for sorted input; search the whole hull
-            int u = next_[hint];
-            while (u != hint && !sees(u, q)) u = next_[u];
-            if (!sees(u, q)) return;
-            first = u;
+        else {                            // look both ways from the hint: the visible chain is near it
+            int f = hint, b = hint;
+            for (;;) {
+                b = prev_[b];
+                if (sees(b, q)) { first = b; break; }
+                if (b == f) return;       // the whole hull was visited: q sees no edge (not expected for a point outside)
+                f = next_[f];
+                if (sees(f, q)) { first = f; break; }
+                if (f == b) return;
+            }
         }
         while (sees(prev_[first], q)) first = prev_[first];
         int u = first, prev_tri = -1, first_tri = -1;
         while (sees(u, q)) {
+            if (u != first) on_hull_[u] = 0;                         // swallowed by the fan
             const int w = next_[u];
             const int old = hull_tri_[u];
             const int cur = new_tri(u, q, w);                        // counter-clockwise, see orient(u, w, q) < 0
@@ -121,6 +186,8 @@ private:
         next_[first] = q; prev_[q] = first; next_[q] = last; prev_[last] = q;
         hull_tri_[first] = first_tri;
         hull_tri_[q] = prev_tri;
+        on_hull_[q] = 1;
+        hash_[hash_key(p[q])] = q;
         legalise();
     }
 
@@ -144,7 +211,7 @@ private:
             if (t2 < 0) continue;
             const int e2 = slot_of_neighbour(t[t2], t1);
             const int p1 = t[t1].v[e1], a = t[t1].v[(e1 + 1) % 3], b = t[t1].v[(e1 + 2) % 3], p2 = t[t2].v[e2];
-            if (in_circle(p[p1], p[a], p[b], p[p2]) <= 0) continue;
+            if ((small_ ? in_circle_small(p[p1], p[a], p[b], p[p2]) : in_circle(p[p1], p[a], p[b], p[p2])) <= 0) continue;
             // quad p1, a, p2, b (counter-clockwise): replace diagonal (a, b) by (p1, p2)
             const int n_p1a = t[t1].n[(e1 + 2) % 3], n_bp1 = t[t1].n[(e1 + 1) % 3];
             const int n_p2b = t[t2].n[(e2 + 2) % 3], n_ap2 = t[t2].n[(e2 + 1) % 3];
@@ -184,9 +251,20 @@ int triangulate(const int32_t *xy, int n, std::vector<TriOut> &out) {
         const int lead = v[0] < v[1] ? (v[0] < v[2] ? 0 : 2) : (v[1] < v[2] ? 1 : 2);
         for (int k = 0; k < 3; ++k) out[i].v[k] = v[(lead + k) % 3];
     }
-    std::sort(out.begin(), out.end(), [](const TriOut &a, const TriOut &b) {
-        return a.v[0] != b.v[0] ? a.v[0] < b.v[0] : (a.v[1] != b.v[1] ? a.v[1] < b.v[1] : a.v[2] < b.v[2]);
-    });
+    if (n <= (1 << 21)) {
+        // three 21-bit indices in one 64-bit key: the lexicographic order, sorted as plain integers
+        std::vector<uint64_t> keys(out.size());
+        for (size_t i = 0; i < out.size(); ++i)
+            keys[i] = ((uint64_t)out[i].v[0] << 42) | ((uint64_t)out[i].v[1] << 21) | (uint64_t)out[i].v[2];
+        std::sort(keys.begin(), keys.end());
+        for (size_t i = 0; i < out.size(); ++i) {
+            out[i].v[0] = (int)(keys[i] >> 42); out[i].v[1] = (int)((keys[i] >> 21) & 0x1fffff); out[i].v[2] = (int)(keys[i] & 0x1fffff);
+        }
+    } else {
+        std::sort(out.begin(), out.end(), [](const TriOut &a, const TriOut &b) {
+            return a.v[0] != b.v[0] ? a.v[0] < b.v[0] : (a.v[1] != b.v[1] ? a.v[1] < b.v[1] : a.v[2] < b.v[2]);
+        });
+    }
     return 0;
 }
 

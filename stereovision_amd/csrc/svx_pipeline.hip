@@ -5,7 +5,6 @@
 #include "svx_common.hpp"
 #include <algorithm>
 #include <chrono>
-#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -92,8 +91,8 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     // one device allocation for every intermediate image and list; laid out twice (measure, then place)
     uint8_t *L, *Rr, *La, *Ra, *grad;
     uint32_t *cL, *cR;
-    int32_t *pts, *kpl, *kpr, *conf_x, *conf_y, *inv_x, *inv_y, *rs_xy;
-    float *respl, *respr, *disparities, *final_disp, *conf_d, *rs_d;
+    int32_t *pts, *kpl, *kpr, *conf_x, *conf_y, *inv_x, *inv_y, *rs_xy, *stage_xy;
+    float *respl, *respr, *disparities, *final_disp, *conf_d, *rs_d, *stage_d;
     int8_t *costs, *final_costs, *conf_c, *inv_c;
     uint8_t *rs_valid;
     auto layout = [&](Arena &a) {
@@ -108,6 +107,7 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         conf_d = a.take<float>(cells_needed);
         conf_c = a.take<int8_t>(cells_needed); inv_c = a.take<int8_t>(cells_needed);
         rs_xy = a.take<int32_t>(4 * cells_needed); rs_d = a.take<float>(2 * cells_needed); rs_valid = a.take<uint8_t>(2 * cells_needed);
+        stage_xy = a.take<int32_t>(2 * n); stage_d = a.take<float>(n);      // host-made point lists (at most one point a pixel)
     };
     Arena measure;
     layout(measure);
@@ -169,9 +169,10 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     // support points of the mesh, in insertion order, repeated positions dropped (.cpp:434-445)
     std::vector<int32_t> sup;                 // x,y pairs
     std::vector<float> sup_d;
-    std::unordered_set<int64_t> seen;
+    std::vector<uint8_t> seen(n, 0);
     auto insert_point = [&](int x, int y) {
-        if (seen.insert((int64_t)y * Cc + x).second) { sup.push_back(x); sup.push_back(y); }
+        uint8_t &s = seen[(size_t)y * Cc + x];
+        if (!s) { s = 1; sup.push_back(x); sup.push_back(y); }
     };
     std::vector<int32_t> sxy;
     for (int i = 0; i < n_rec; ++i) {
@@ -185,19 +186,12 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     auto upload_scatter = [&](const std::vector<int32_t> &xy, const std::vector<float> &d) -> int {
         const int m = (int)d.size();
         if (!m) return SVX_OK;
-        void *tmp = nullptr;
-        if (hipMalloc(&tmp, (size_t)m * 12) != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: support staging");
-        int32_t *dxy = (int32_t *)tmp;
-        float *dd = (float *)((char *)tmp + (size_t)m * 8);
-        hipError_t e = hipMemcpyAsync(dxy, xy.data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(dd, d.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) {
-            scatter_support_kernel<<<svx_cdiv(m, 256), 256, 0, ctx->stream>>>(dxy, dd, m, Cc, disparities);
-            e = hipGetLastError();
-        }
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(tmp);
-        return e == hipSuccess ? SVX_OK : svx_fail(ctx, SVX_ERR_HIP, "svx_high_perf_stereo: support upload: %s", hipGetErrorString(e));
+        SVX_HIP(ctx, hipMemcpyAsync(stage_xy, xy.data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+        SVX_HIP(ctx, hipMemcpyAsync(stage_d, d.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+        scatter_support_kernel<<<svx_cdiv(m, 256), 256, 0, ctx->stream>>>(stage_xy, stage_d, m, Cc, disparities);
+        SVX_LAUNCH_CHECK(ctx, "scatter_support_kernel");
+        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the host vectors go out of scope
+        return SVX_OK;
     };
     SVX_TRY(upload_scatter(sxy, sup_d));
 
@@ -238,16 +232,9 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     // the support points themselves end up in the map, truncated to integers, and in the point list (.cpp:624-637)
     const int n_sup = (int)(sup.size() / 2);
     if (n_sup) {
-        void *tmp = nullptr;
-        if (hipMalloc(&tmp, (size_t)n_sup * 8) != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: vertex staging");
-        hipError_t e = hipMemcpyAsync(tmp, sup.data(), (size_t)n_sup * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) {
-            vertex_disparities_kernel<<<svx_cdiv(n_sup, 256), 256, 0, ctx->stream>>>((const int32_t *)tmp, n_sup, Cc, disparities, final_disp);
-            e = hipGetLastError();
-        }
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(tmp);
-        if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_HIP, "svx_high_perf_stereo: vertex pass: %s", hipGetErrorString(e));
+        SVX_HIP(ctx, hipMemcpyAsync(stage_xy, sup.data(), (size_t)n_sup * 8, hipMemcpyHostToDevice, ctx->stream));
+        vertex_disparities_kernel<<<svx_cdiv(n_sup, 256), 256, 0, ctx->stream>>>(stage_xy, n_sup, Cc, disparities, final_disp);
+        SVX_LAUNCH_CHECK(ctx, "vertex_disparities_kernel");
     }
     SVX_HIP(ctx, hipMemcpy2DAsync(disparity_map, (size_t)cols * 4, final_disp, (size_t)Cc * 4, (size_t)Cc * 4, R, hipMemcpyDeviceToDevice, ctx->stream));
 
