@@ -367,6 +367,75 @@ inline ConfidentSupport epipolarMatching(const MatU32 &censusLeft, const MatU32 
     return ConfidentSupport(leftPoint.x, leftPoint.y, d, (char)c);
 }
 
+// Support-point mesh with the two operations the pipeline needs from Fade_2D (highPerfStereoLib.cpp:434-445, :457):
+// insert a point, list the triangles.  Points are kept in insertion order without repeats; triangles() runs libsvx's
+// exact Delaunay triangulation (index triples into points()).
+namespace svx {
+class Mesh {
+public:
+    void insert(const Point &p) {
+        for (size_t i = 0; i < pts.size(); ++i) if (pts[i].x == p.x && pts[i].y == p.y) return;
+        pts.push_back(p);
+    }
+    const std::vector<Point> &points() const { return pts; }
+    std::vector<int32_t> triangles() const {
+        std::vector<int32_t> xy = flatten_points(pts), tri(6 * pts.size() + 3);
+        int n = 0;
+        Runtime::check(svx_delaunay(Runtime::ctx(), xy.data(), (int)pts.size(), tri.data(), (int)(tri.size() / 3), &n));
+        tri.resize(3 * (size_t)n);
+        return tri;
+    }
+private:
+    std::vector<Point> pts;
+};
+// How supportResampling hands a new support point to the mesh.  The default fits svx::Mesh and any type with
+// insert(svx::Point); a caller that keeps Fade2D adds, before including this header's users,
+//   namespace svx { inline void mesh_insert(GEOM_FADE2D::Fade_2D &m, int x, int y) { GEOM_FADE2D::Point2 p(x, y); m.insert(p); } }
+template <class MeshT>
+inline void mesh_insert(MeshT &mesh, int x, int y) { mesh.insert(Point(x, y)); }
+}  // namespace svx
+
+// highPerfStereoLib.h:216-222  supportResampling(mesh, ps, censusLeft, censusRight, censusSize, costAggrWindowSize,
+//                                                disparities, tLow, tHigh, maxDisp)
+// The reference's first parameter is a Fade_2D&; here it is any mesh type (see svx::mesh_insert).  The new points are
+// written into `disparities` and inserted in the reference's order (row-major cells; re-matched invalid point first,
+// then the confident support, highPerfStereoLib.cpp:151-173).
+template <class MeshT, class MatU32, class MatF32>
+inline void supportResampling(MeshT &mesh, PotentialSupports &ps, const MatU32 &censusLeft, const MatU32 &censusRight,
+                              int censusSize, int costAggrWindowSize, MatF32 &disparities, char tLow, char tHigh, int maxDisp) {
+    const int rows = censusLeft.rows, cols = censusLeft.cols;
+    const int gw = (int)ps.getOccGridWidth(), gh = (int)ps.getOccGridHeight();
+    const size_t nc = (size_t)gw * gh;
+    std::vector<int32_t> cx(nc), cy(nc), ix(nc), iy(nc);
+    std::vector<float> cd(nc);
+    std::vector<int8_t> cc(nc), ic(nc);
+    for (int j = 0; j < gh; ++j)
+        for (int i = 0; i < gw; ++i) {
+            const size_t c = (size_t)j * gw + i;
+            const ConfidentSupport s = ps.getConfidentSupport(i, j);
+            const InvalidMatch m = ps.getInvalidMatch(i, j);
+            cx[c] = s.x; cy[c] = s.y; cd[c] = s.disparity; cc[c] = (int8_t)s.cost;
+            ix[c] = m.x; iy[c] = m.y; ic[c] = (int8_t)m.cost;
+        }
+    svx::DeviceImage<uint32_t> dl(rows, cols), dr(rows, cols);
+    svx::DeviceImage<float> dd(rows, cols);
+    dl.upload(censusLeft); dr.upload(censusRight); dd.upload(disparities);
+    svx::DeviceArray<int32_t> dcx(nc), dcy(nc), dix(nc), diy(nc), oxy(4 * nc);
+    svx::DeviceArray<float> dcd(nc), od(2 * nc);
+    svx::DeviceArray<int8_t> dcc(nc), dic(nc);
+    svx::DeviceArray<uint8_t> ov(2 * nc);
+    dcx.upload(cx.data()); dcy.upload(cy.data()); dcd.upload(cd.data()); dcc.upload(cc.data());
+    dix.upload(ix.data()); diy.upload(iy.data()); dic.upload(ic.data());
+    svx::Runtime::check(svx_support_resampling(svx::Runtime::ctx(), dl.d, dr.d, rows, cols, censusSize, costAggrWindowSize, gw, gh,
+                                               dcx.d, dcy.d, dcd.d, dcc.d, dix.d, diy.d, dic.d, tLow, tHigh, maxDisp, dd.d, oxy.d, od.d, ov.d));
+    dd.download(disparities);
+    std::vector<int32_t> hxy(4 * nc);
+    std::vector<uint8_t> hv(2 * nc);
+    oxy.download(hxy.data()); ov.download(hv.data());
+    for (size_t s = 0; s < 2 * nc; ++s)
+        if (hv[s]) svx::mesh_insert(mesh, hxy[2 * s], hxy[2 * s + 1]);
+}
+
 // denseCensusStereo/denseCensusStereo.cpp:257-266: the dense winner-takes-all driver loop as one call
 // (census images in, float disparity map out; only interior pixels are written, as in the reference).
 template <class MatU32, class MatF32>

@@ -84,6 +84,17 @@ int main() {
         InvalidMatch im = ps.getInvalidMatch(2, 0);
         CHECK(cs.x == 44 && cs.y == 8 && std::fabs(cs.disparity - 4.256f) < 1e-4f && cs.cost == 0);
         CHECK(im.x == 41 && im.y == 14 && im.cost == 24);
+        {   // supportResampling on the grid just built: the confident supports (cost < tLow) enter the mesh and the prior
+            svx::Mesh mesh;
+            MatF32 prior2 = prior;
+            supportResampling(mesh, ps, censusLeft, censusRight, 5, 11, prior2, 2, 10, 24);
+            CHECK(mesh.points().size() >= 3);
+            bool has_cell20 = false;
+            for (size_t i = 0; i < mesh.points().size(); ++i) has_cell20 = has_cell20 || (mesh.points()[i].x == 44 && mesh.points()[i].y == 8);
+            CHECK(has_cell20 && std::fabs(prior2(8, 44) - 4.256f) < 1e-4f);
+            std::vector<int32_t> tri = mesh.triangles();
+            CHECK(tri.size() % 3 == 0 && tri.size() >= 3);
+        }
         ConfidentSupport e1 = epipolarMatching(censusLeft, censusRight, 5, 11, InvalidMatch(40, 12, 0), 24);
         ConfidentSupport e2 = epipolarMatching(censusLeft, censusRight, 5, 11, InvalidMatch(9, 20, 0), 24);
         CHECK(e1.disparity == 4.0f && e1.cost == 0 && e2.disparity == 1.0f && e2.cost == 12);
