@@ -82,6 +82,71 @@ def cpu_baseline_9x7(left, right, D, n_frames_work, lr, lr_threshold):
     }, want, nrows
 
 
+def host_threads():
+    """Worker threads for the all-cores CPU leg: the box's CPU share (OMP_NUM_THREADS there), within the affinity mask."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    want = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return max(1, min(avail, want if want > 0 else avail, 64))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_threads(left, right, D, variant, lr, lr_threshold, frames_per_thread):
+    """The same oracle routines on every host core of this process's share: plain threads, one band of rows each (ctypes
+    releases the GIL inside the C routines).  Returns the cpu_baseline-shaped dict."""
+    import threading
+    import oracle_lib as O
+    rows, cols = left.shape
+    T = host_threads()
+    if variant == "5x5":
+        cl, cr = O.census5x5(O.u8_to_s8(left)), O.census5x5(O.u8_to_s8(right))
+    else:
+        cl, cr = O.census9x7(left), O.census9x7(right)
+    total_rows = max(1, int(round(frames_per_thread * (rows - 4))))
+
+    def work():
+        done = 0
+        out = np.zeros((rows, cols), np.float32)
+        while done < total_rows:
+            take = min(rows - 4, total_rows - done)
+            if variant == "5x5":
+                O.lib.orc_dense_wta5x5_rows(cl.ctypes.data, cr.ctypes.data, rows, cols, D, out.ctypes.data, 2, 2 + take)
+            else:
+                w = O.dense_wta_words(cl, cr, D, 0, 2, 2 + take)
+                if lr:
+                    O.lr_check(w, O.dense_wta_words(cl, cr, D, 1, 2, 2 + take), lr_threshold, -1.0)
+            done += take
+
+    threads = [threading.Thread(target=work) for _ in range(T)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    secs = time.perf_counter() - t0
+    frames = T * total_rows / float(rows - 4)
+    return {
+        "value": round(rows * cols * D * frames / secs / 1e6, 2),
+        "unit": "Mpix*disp/s",
+        "cores": T,
+        "kind": "port",
+        "cpu": cpu_model(),
+        "sample": "%.2f frames of %dx%d D=%d over %d threads (dense search rows only, census excluded), oracle/svx_oracle.c, %.1f s"
+                  % (frames, cols, rows, D, T, secs),
+    }
+
+
 def cpu_baseline(left, right, D, n_frames_work):
     """Times the CPU oracle (a port of the reference's scalar loops) on a bounded sample, 1 thread."""
     import oracle_lib as O
@@ -252,6 +317,7 @@ def main():
 
         # ---- CPU baseline (oracle port, 1 thread) + parity spot check on the same frame ----
         cpu = None
+        cpu_all = None
         parity = "not checked"
         if args.cpu_frames > 0 and world == 1:
             step()                                 # the timing launches above reused `disp`
@@ -260,6 +326,13 @@ def main():
                 cpu, want, nrows = cpu_baseline(ls[0], rs[0], D, args.cpu_frames)
             else:
                 cpu, want, nrows = cpu_baseline_9x7(ls[0], rs[0], D, args.cpu_frames / (8.0 if lr else 4.0), lr, args.lr_threshold)
+            cpu["cpu"] = cpu_model()
+            # the same port on every core of the host share, beside the one-thread figure
+            per_thread = {"5x5": 1.0, "9x7": 0.25, "9x7lr": 0.125}[variant] * args.cpu_frames / 4.0
+            try:
+                cpu_all = cpu_baseline_threads(ls[0], rs[0], D, variant, lr, args.lr_threshold, per_thread)
+            except Exception as e:  # reported baseline only
+                cpu_all = {"error": type(e).__name__}
             got = disp[0].cpu().numpy()
             same = bool(np.array_equal(got[2:2 + nrows], want[2:2 + nrows]))
             parity = "bit-exact vs oracle on frame 0 rows 2..%d" % (1 + nrows) if same else "MISMATCH vs oracle on frame 0"
@@ -288,6 +361,7 @@ def main():
                        "parallelism": "frames x%d" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "parity": parity,
             "gather_to_gpu0_ms": gather_ms,
         }
