@@ -127,24 +127,32 @@ __device__ __forceinline__ uint32_t reduce16(const uint32_t (&k)[SW_T], int lane
 // words, skewed by its disparity (lane l reads column xq + 63 - l + j).
 // WORDS = 32-bit words per census descriptor; a staged row holds the descriptors of consecutive columns
 // back to back (WORDS words each), so a two-word descriptor is one 64-bit LDS access.
-template <int WORDS>
+// GROUPS > 1 folds the row in column groups (loads of a group, then its popcounts) so that fewer right words are live
+// at once; used where registers, not latency, limit the kernel.
+template <int WORDS, int GROUPS = 1>
 __device__ __forceinline__ void sweep_row_accumulate(SweepState &st, const uint32_t (&cl)[SW_C * WORDS], const uint32_t *__restrict__ rp) {
-    uint32_t cr[SW_C][WORDS];
+    constexpr int PER = SW_C / GROUPS;
+    static_assert(SW_C % GROUPS == 0, "column groups must divide the row");
 #pragma unroll
-    for (int j = 0; j < SW_C; ++j) {
-        if (WORDS == 1) {
-            cr[j][0] = rp[j];
-        } else {
-            const uint2 v = *reinterpret_cast<const uint2 *>(rp + 2 * j);
-            cr[j][0] = v.x; cr[j][WORDS - 1] = v.y;
+    for (int g0 = 0; g0 < SW_C; g0 += PER) {
+        uint32_t cr[PER][WORDS];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (WORDS == 1) {
+                cr[j][0] = rp[g0 + j];
+            } else {
+                const uint2 v = *reinterpret_cast<const uint2 *>(rp + 2 * (g0 + j));
+                cr[j][0] = v.x; cr[j][WORDS - 1] = v.y;
+            }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < SW_C; ++j) {
-        st.C[j] += (uint32_t)__builtin_popcount(cl[j * WORDS] ^ cr[j][0]);
+        for (int j = 0; j < PER; ++j) {
+            st.C[g0 + j] += (uint32_t)__builtin_popcount(cl[(g0 + j) * WORDS] ^ cr[j][0]);
 #pragma unroll
-        for (int w = 1; w < WORDS; ++w)   // keep the accumulating popcount: left to itself the compiler sums the counts with extra adds
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(st.C[j]) : "v"(cl[j * WORDS + w] ^ cr[j][w]), "v"(st.C[j]));
+            for (int w = 1; w < WORDS; ++w)   // keep the accumulating popcount: left to itself the compiler sums the counts with extra adds
+                asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(st.C[g0 + j]) : "v"(cl[(g0 + j) * WORDS + w] ^ cr[j][w]), "v"(st.C[g0 + j]));
+        }
+        if (GROUPS > 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -157,6 +165,9 @@ __device__ __forceinline__ void sweep_row_accumulate(SweepState &st, const uint3
 // diagonal that ends at (column 15, lane l), and lane 63 of k[i], i < 15, that of the diagonal leaving the tile
 // at column i.  These 79 partial minima are stored for svx's merge pass (one tile covers only 16 of the up to
 // max_disp columns of a diagonal).
+#ifndef SVX_BOTH_GROUPS
+#define SVX_BOTH_GROUPS 2       // column groups of the row accumulation in the both-views kernel (measured best with 3 wavefronts/SIMD)
+#endif
 constexpr int SW_PART = 80;          // partial minima stored per (row, x-block, chunk): 64 + 15, padded
 template <bool IS_MAX>
 __device__ __forceinline__ uint32_t diag_step(uint32_t run, uint32_t key) {
@@ -317,7 +328,7 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
 #define SVX_ROW(RR)                                                                                   \
     {                                                                                                 \
         const int r = r0 + RR;                                                                        \
-        sweep_row_accumulate<WORDS>(st, lw, st_r + (RR % SW_SLOTS) * SLOT_STRIDE);                    \
+        sweep_row_accumulate<WORDS, (BOTH ? SVX_BOTH_GROUPS : 1)>(st, lw, st_r + (RR % SW_SLOTS) * SLOT_STRIDE); \
         fetch_left(min(r + 1, last), lw);                                                             \
         stash((RR + 2) % SW_SLOTS, g);                                                                \
         fetch(min(r + 3, last), g);                                                                   \
@@ -478,7 +489,7 @@ static int launch_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     static const int occ = [] { const char *e = getenv("SVX_SWEEP_OCC"); return e ? atoi(e) : 3; }();
     if (partial) {
         if (MIRROR) return svx_fail(ctx, SVX_ERR_INVALID_ARG, "both-view sweep runs in the left view");
-        static const int occ_both = [] { const char *e = getenv("SVX_SWEEP_OCC_BOTH"); return e ? atoi(e) : 2; }();
+        static const int occ_both = [] { const char *e = getenv("SVX_SWEEP_OCC_BOTH"); return e ? atoi(e) : 3; }();
         if (occ_both == 3)
             dense_wta5x5_sweep_kernel<3, WORDS, false, true><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border, partial);
         else
