@@ -165,6 +165,9 @@ __device__ __forceinline__ void sweep_row_accumulate(SweepState &st, const uint3
 // diagonal that ends at (column 15, lane l), and lane 63 of k[i], i < 15, that of the diagonal leaving the tile
 // at column i.  These 79 partial minima are stored for svx's merge pass (one tile covers only 16 of the up to
 // max_disp columns of a diagonal).
+#ifndef SVX_BASE_GROUPS
+#define SVX_BASE_GROUPS 1
+#endif
 #ifndef SVX_BOTH_GROUPS
 #define SVX_BOTH_GROUPS 2       // column groups of the row accumulation in the both-views kernel (measured best with 3 wavefronts/SIMD)
 #endif
@@ -328,7 +331,7 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
 #define SVX_ROW(RR)                                                                                   \
     {                                                                                                 \
         const int r = r0 + RR;                                                                        \
-        sweep_row_accumulate<WORDS, (BOTH ? SVX_BOTH_GROUPS : 1)>(st, lw, st_r + (RR % SW_SLOTS) * SLOT_STRIDE); \
+        sweep_row_accumulate<WORDS, (BOTH ? SVX_BOTH_GROUPS : SVX_BASE_GROUPS)>(st, lw, st_r + (RR % SW_SLOTS) * SLOT_STRIDE); \
         fetch_left(min(r + 1, last), lw);                                                             \
         stash((RR + 2) % SW_SLOTS, g);                                                                \
         fetch(min(r + 3, last), g);                                                                   \
