@@ -111,7 +111,7 @@ def test_fused_census9x7_lr(ctx, rows, cols, max_disp, thr):
 
 
 # ------------------------------------------------------------------ sub-pixel refinement (build-defined)
-SUBPIXEL_TOL = 1e-3   # px, the tolerance BASELINE.json states for sub-pixel disparities; the results are in fact identical
+SUBPIXEL_TOL = 1e-3   # px, the tolerance required of sub-pixel disparities; the results are in fact identical
 
 
 @pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (30, 150, 128), (9, 21, 5), (5, 20, 8), (64, 300, 200), (4, 30, 4)])
@@ -156,7 +156,7 @@ def test_fused_census9x7_subpixel(ctx, rows, cols, max_disp):
 
 
 def test_subpixel_4k_512_disparities(ctx):
-    """configs[4] size (3840x2160, D=512): the fused run against the oracle on a band of rows, and the sub-pixel step
+    """The 3840x2160, D=512 configuration: the fused run against the oracle on a band of rows, and the sub-pixel step
     against the oracle on the whole frame starting from the device's own integer map."""
     from stereovision_amd import synth
     import stereovision_amd as S
@@ -178,7 +178,7 @@ def test_subpixel_4k_512_disparities(ctx):
 
 @pytest.mark.parametrize("frames,rows,cols,D,band", [(2, 1072, 1920, 256, (500, 503)), (1, 2160, 3840, 512, (1000, 1002))])
 def test_left_right_full_size_configs(ctx, frames, rows, cols, D, band):
-    """configs[3] (1920x1080 cropped to /16, D=256) and configs[4] (3840x2160, D=512) through the fused left-right entry
+    """The 1920x1080 (cropped to /16, D=256) and 3840x2160 (D=512) configurations through the fused left-right entry
     point: against the oracle on a band of rows of every frame; the pixels the check rejects are exactly those where the two
     separately computed views disagree (whole frame, device results of the one-view searches)."""
     import stereovision_amd as S

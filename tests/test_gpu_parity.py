@@ -364,7 +364,7 @@ def test_cpp_reference_api_program():
 # ------------------------------------------------------------------ full benchmark sizes of the other configs
 @pytest.mark.parametrize("rows,cols,D,check_rows", [(1072, 1920, 256, (500, 503)), (2160, 3840, 512, (1000, 1002))])
 def test_dense_wta_full_size_configs(ctx, rows, cols, D, check_rows):
-    """configs[3] (1920x1080 cropped to /16, D=256) and configs[4] (3840x2160, D=512): border, range and a
+    """The 1920x1080 (cropped to /16, D=256) and 3840x2160 (D=512) configurations: border, range and a
     few complete rows against the oracle (rows are independent given the census images)."""
     from stereovision_amd import synth
     left, right, field = synth.stereo_pair(rows, cols, D, seed=7)

@@ -1,4 +1,4 @@
-"""GPU parity of the full highPerfStereo() pipeline (BASELINE configs[2]) through the C ABI against the
+"""GPU parity of the full highPerfStereo() pipeline through the C ABI against the
 oracle composition of tests/oracle_pipeline.py, bit-exact: disparity map, computed points, and the
 intermediate counts.  Parity status: the pipeline's OpenCV steps and the mesh are unpinned on reference
 outputs (OpenCV and Fade2D are not available); the census / matching / refinement steps are the pinned

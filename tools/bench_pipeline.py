@@ -1,4 +1,4 @@
-"""Times svx_high_perf_stereo (the full support-point / plane-prior pipeline, BASELINE configs[2]) on KITTI-size
+"""Times svx_high_perf_stereo (the full support-point / plane-prior pipeline of the reference) on KITTI-size
 synthetic pairs and, beside it, the CPU oracle composition of the same pipeline.  Measurement aid (run on the GPU box)."""
 import json
 import os
