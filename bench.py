@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--variant", choices=["9x7lr", "9x7", "5x5"], default="9x7lr")
     ap.add_argument("--lr-threshold", type=float, default=1.0)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend; gloo with --one-device rehearses the multi-rank path on a one-GPU box")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     return ap.parse_args()
 
 
@@ -186,10 +189,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.one_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -230,7 +238,8 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     barrier()
-    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where the collectives' tensors live
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, coll_dev)
 
     pixdisp_per_frame = rows * cols * D
     value = sharding.throughput_mpixdisp(rows, cols, D, F, world, args.steps, elapsed)
@@ -243,7 +252,7 @@ def main():
             torch.cuda.synchronize(dev)
             barrier()
             g0 = time.perf_counter()
-            sharding.gather_to_rank0(disp)
+            sharding.gather_to_rank0(disp if args.backend == "nccl" else disp.cpu())
             torch.cuda.synchronize(dev)
             barrier()
             gather_ms = (time.perf_counter() - g0) * 1e3
