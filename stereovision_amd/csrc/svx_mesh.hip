@@ -20,7 +20,7 @@ namespace {
 typedef long long i64;
 typedef __int128 i128;
 
-struct Pt { i64 x, y; int id; };
+struct Pt { i64 x, y; int id; i64 d2; };    // d2: squared distance from the centre of the radial order (set by build)
 
 inline i64 orient(const Pt &a, const Pt &b, const Pt &c) { return (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x); }
 
@@ -50,31 +50,33 @@ public:
     std::vector<Tri> t;
     bool small_ = false;                 // every |coordinate| <= 2^13: the 64-bit circle test is exact
 
+    // p: the caller's points in any order, repeats allowed (the copy with the smallest id is kept)
     void build() {
-        const int n = (int)p.size();
+        if (p.empty()) return;
         small_ = true;
         for (const Pt &q : p) small_ = small_ && q.x >= -8192 && q.x <= 8192 && q.y >= -8192 && q.y <= 8192;
-        t.reserve(2 * (size_t)n);
-        next_.assign(n, -1); prev_.assign(n, -1); hull_tri_.assign(n, -1); on_hull_.assign(n, 0);
-        if (n < 3) return;
         // Radial order around the input point nearest the middle of the bounding box (exact integer distances): the
         // points before any point q lie in the closed disc through q, so q lies outside their hull, and the hull grows
-        // as a blob instead of a sliver, which keeps the number of flips per point small.
+        // as a blob instead of a sliver, which keeps the number of flips per point small.  The same sort brings
+        // repeated positions together.
         i64 x0 = p[0].x, x1 = p[0].x, y0 = p[0].y, y1 = p[0].y;
         for (const Pt &q : p) { x0 = std::min(x0, q.x); x1 = std::max(x1, q.x); y0 = std::min(y0, q.y); y1 = std::max(y1, q.y); }
-        int c = 0;
+        size_t c = 0;
         i64 best = -1;
-        for (int i = 0; i < n; ++i) {
+        for (size_t i = 0; i < p.size(); ++i) {
             const i64 dx = 2 * p[i].x - (x0 + x1), dy = 2 * p[i].y - (y0 + y1), d2 = dx * dx + dy * dy;
             if (best < 0 || d2 < best) { best = d2; c = i; }
         }
         centre_ = p[c];
-        const Pt ctr = centre_;
-        std::sort(p.begin(), p.end(), [ctr](const Pt &a, const Pt &b) {
-            const i64 da = (a.x - ctr.x) * (a.x - ctr.x) + (a.y - ctr.y) * (a.y - ctr.y);
-            const i64 db = (b.x - ctr.x) * (b.x - ctr.x) + (b.y - ctr.y) * (b.y - ctr.y);
-            return da != db ? da < db : (a.x != b.x ? a.x < b.x : a.y < b.y);
+        for (Pt &q : p) q.d2 = (q.x - centre_.x) * (q.x - centre_.x) + (q.y - centre_.y) * (q.y - centre_.y);
+        std::sort(p.begin(), p.end(), [](const Pt &a, const Pt &b) {
+            return a.d2 != b.d2 ? a.d2 < b.d2 : (a.x != b.x ? a.x < b.x : (a.y != b.y ? a.y < b.y : a.id < b.id));
         });
+        p.erase(std::unique(p.begin(), p.end(), [](const Pt &a, const Pt &b) { return a.x == b.x && a.y == b.y; }), p.end());
+        const int n = (int)p.size();
+        t.reserve(2 * (size_t)n);
+        next_.assign(n, -1); prev_.assign(n, -1); hull_tri_.assign(n, -1); on_hull_.assign(n, 0);
+        if (n < 3) return;
         int k = 2;                       // p[0..k) is the leading collinear run
         while (k < n && orient(p[0], p[1], p[k]) == 0) ++k;
         if (k == n) return;              // every point on one line: no triangle
@@ -240,31 +242,31 @@ int triangulate(const int32_t *xy, int n, std::vector<TriOut> &out) {
         pts[i].x = xy[2 * i]; pts[i].y = xy[2 * i + 1]; pts[i].id = i;
         if (pts[i].x < -(1 << 23) || pts[i].x > (1 << 23) || pts[i].y < -(1 << 23) || pts[i].y > (1 << 23)) return -1;
     }
-    std::sort(pts.begin(), pts.end(), [](const Pt &a, const Pt &b) { return a.x != b.x ? a.x < b.x : (a.y != b.y ? a.y < b.y : a.id < b.id); });
     Delaunay d;
-    for (int i = 0; i < n; ++i)
-        if (d.p.empty() || d.p.back().x != pts[i].x || d.p.back().y != pts[i].y) d.p.push_back(pts[i]);
+    d.p.swap(pts);
     d.build();
-    out.resize(d.t.size());
-    for (size_t i = 0; i < d.t.size(); ++i) {
-        int v[3] = {d.p[d.t[i].v[0]].id, d.p[d.t[i].v[1]].id, d.p[d.t[i].v[2]].id};
+    // canonical form: every triple led by its smallest index, the list in lexicographic order.  Counting sort by the
+    // leading index (a point leads only a handful of triangles), then each small bucket by the other two.
+    const size_t nt = d.t.size();
+    std::vector<TriOut> tmp(nt);
+    std::vector<int> start((size_t)n + 1, 0);
+    for (size_t i = 0; i < nt; ++i) {
+        const int v[3] = {d.p[d.t[i].v[0]].id, d.p[d.t[i].v[1]].id, d.p[d.t[i].v[2]].id};
         const int lead = v[0] < v[1] ? (v[0] < v[2] ? 0 : 2) : (v[1] < v[2] ? 1 : 2);
-        for (int k = 0; k < 3; ++k) out[i].v[k] = v[(lead + k) % 3];
+        for (int k = 0; k < 3; ++k) tmp[i].v[k] = v[(lead + k) % 3];
+        ++start[(size_t)tmp[i].v[0] + 1];
     }
-    if (n <= (1 << 21)) {
-        // three 21-bit indices in one 64-bit key: the lexicographic order, sorted as plain integers
-        std::vector<uint64_t> keys(out.size());
-        for (size_t i = 0; i < out.size(); ++i)
-            keys[i] = ((uint64_t)out[i].v[0] << 42) | ((uint64_t)out[i].v[1] << 21) | (uint64_t)out[i].v[2];
-        std::sort(keys.begin(), keys.end());
-        for (size_t i = 0; i < out.size(); ++i) {
-            out[i].v[0] = (int)(keys[i] >> 42); out[i].v[1] = (int)((keys[i] >> 21) & 0x1fffff); out[i].v[2] = (int)(keys[i] & 0x1fffff);
-        }
-    } else {
-        std::sort(out.begin(), out.end(), [](const TriOut &a, const TriOut &b) {
-            return a.v[0] != b.v[0] ? a.v[0] < b.v[0] : (a.v[1] != b.v[1] ? a.v[1] < b.v[1] : a.v[2] < b.v[2]);
-        });
+    for (int i = 0; i < n; ++i) start[(size_t)i + 1] += start[i];
+    out.resize(nt);
+    {
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (size_t i = 0; i < nt; ++i) out[(size_t)fill[tmp[i].v[0]]++] = tmp[i];
     }
+    for (int i = 0; i < n; ++i)
+        if (start[(size_t)i + 1] - start[i] > 1)
+            std::sort(out.begin() + start[i], out.begin() + start[(size_t)i + 1], [](const TriOut &a, const TriOut &b) {
+                return a.v[1] != b.v[1] ? a.v[1] < b.v[1] : a.v[2] < b.v[2];
+            });
     return 0;
 }
 

@@ -162,8 +162,9 @@ SVX_API int svx_sparse_match(svx_ctx *ctx, const uint32_t *census_left, const ui
             return a < b;
         };
     };
-    std::sort(lo.begin(), lo.end(), by_yx(left_xy_host));
-    std::sort(ro.begin(), ro.end(), by_yx(right_xy_host));
+    // detector output is already in raster order: one linear pass then replaces the sort
+    if (!std::is_sorted(lo.begin(), lo.end(), by_yx(left_xy_host))) std::sort(lo.begin(), lo.end(), by_yx(left_xy_host));
+    if (!std::is_sorted(ro.begin(), ro.end(), by_yx(right_xy_host))) std::sort(ro.begin(), ro.end(), by_yx(right_xy_host));
 
     // Row offsets into the sorted right list.
     std::vector<unsigned> offsets(rows);
