@@ -339,13 +339,15 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
         const uint32_t zk = sweep_row_reduce<RR, MASKED, BOTH>(st, lane, (RR & 1) ? d_odd : d, xlim_base, dmax, ilim_right, dep_lds, ro); \
         if (r >= 4 && r < n_rows) {                /* output row y_lo + r - 4 */                      \
             atomicMin(&best[r - 4][lane & 15], zk);                                                   \
-            if (BOTH) {                                                                               \
-                uint32_t *prow = part + (long)(r - 4) * part_row_stride;                              \
-                prow[lane] = ro.main;                                                                 \
-                if (lane < 16) prow[64 + lane] = ro.dep;                                              \
+            if (BOTH) {                /* pp walks down the rows; every lane stores (lanes 16..63 repeat lanes 0..15) */ \
+                pp_main[0] = ro.main;                                                                 \
+                pp_dep[0] = ro.dep;                                                                   \
+                pp_main += part_row_stride;                                                           \
+                pp_dep += part_row_stride;                                                            \
             }                                                                                         \
         }                                                                                             \
     }
+    uint32_t *pp_main = part + lane, *pp_dep = part + 64 + (lane & 15);      // this lane's slots in the current output row
     for (int r0 = 0; r0 < n_rows; r0 += 10) {
         SVX_ROW(0) SVX_ROW(1) SVX_ROW(2) SVX_ROW(3) SVX_ROW(4)
         SVX_ROW(5) SVX_ROW(6) SVX_ROW(7) SVX_ROW(8) SVX_ROW(9)
