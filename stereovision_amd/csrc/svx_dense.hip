@@ -182,11 +182,11 @@ __device__ __forceinline__ uint32_t diag_step(uint32_t run, uint32_t key) {
     return min(sh, key);
 }
 
-struct RightOut { uint32_t main, dep; };   // canonical keys: lane l of main = slot l; lanes 0..14 of dep = slots 64..78
+struct RightOut { uint32_t k[SW_T]; };   // canonical running minima: lane l of k[15] = slot l; lane 63 of k[i], i < 15, = slot 64 + i
 
 template <int R, bool MASKED, bool BOTH>
 __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, uint32_t d, int xlim_base, int dmax,
-                                                     int ilim_right, uint32_t *__restrict__ dep_lds, RightOut &ro) {
+                                                     int ilim_right, RightOut &ro) {
     constexpr int S = R % 5;
     constexpr bool ODD = (R & 1) != 0;
     // prefix sum along x, scaled so that the disparity fits below the cost
@@ -230,17 +230,8 @@ __device__ __forceinline__ uint32_t sweep_row_reduce(SweepState &st, int lane, u
         }
 #pragma unroll
         for (int i = 1; i < SW_T; ++i) kr[i] = diag_step<ODD>(kr[i - 1], kr[i]);
-        // the 15 minima that left through lane 63 are gathered into lanes 0..14 of one register through LDS
-        if (lane == 63) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<uint4 *>(dep_lds + 4 * q) = make_uint4(kr[4 * q], kr[4 * q + 1], kr[4 * q + 2], kr[4 * q + 3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t dv = dep_lds[lane & 15];
-        __builtin_amdgcn_wave_barrier();
-        ro.main = ODD ? (uint32_t)SW_DMASK - kr[SW_T - 1] : kr[SW_T - 1];     // canonical keys: cost << 10 | d
-        ro.dep = ODD ? (uint32_t)SW_DMASK - dv : dv;
+        for (int i = 0; i < SW_T; ++i) ro.k[i] = ODD ? (uint32_t)SW_DMASK - kr[i] : kr[i];     // canonical keys: cost << 10 | d
     }
     return ODD ? (uint32_t)SW_DMASK - z : z;    // canonical key: cost << 10 | d
 }
@@ -254,7 +245,7 @@ template <bool MASKED, int WORDS, bool MIRROR, bool BOTH>
 __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int cols, int max_disp,
                                             int xb, int y_lo, int n_rows, int chunk, int lane,
                                             uint32_t (*stage)[WORDS * SW_SLOT_WORDS], uint32_t (*best)[SW_T],
-                                            uint32_t *__restrict__ dep_lds, uint32_t *__restrict__ part, long part_row_stride) {
+                                            uint32_t *__restrict__ part, long part_row_stride) {
     const int dbase = chunk << 6;
     const uint32_t d = (uint32_t)(dbase + lane);
     const uint32_t d_odd = (uint32_t)SW_DMASK - d;
@@ -336,18 +327,23 @@ __device__ __forceinline__ void sweep_chunk(const uint32_t *__restrict__ cl, con
         stash((RR + 2) % SW_SLOTS, g);                                                                \
         fetch(min(r + 3, last), g);                                                                   \
         RightOut ro;                                                                                  \
-        const uint32_t zk = sweep_row_reduce<RR, MASKED, BOTH>(st, lane, (RR & 1) ? d_odd : d, xlim_base, dmax, ilim_right, dep_lds, ro); \
+        const uint32_t zk = sweep_row_reduce<RR, MASKED, BOTH>(st, lane, (RR & 1) ? d_odd : d, xlim_base, dmax, ilim_right, ro); \
         if (r >= 4 && r < n_rows) {                /* output row y_lo + r - 4 */                      \
             atomicMin(&best[r - 4][lane & 15], zk);                                                   \
-            if (BOTH) {                /* pp walks down the rows; every lane stores (lanes 16..63 repeat lanes 0..15) */ \
-                pp_main[0] = ro.main;                                                                 \
-                pp_dep[0] = ro.dep;                                                                   \
+            if (BOTH) {                /* pp_main walks down the rows */ \
+                pp_main[0] = ro.k[SW_T - 1];                                                          \
+                if (lane == 63) {      /* the diagonals that left the tile through the last lane: slots 64..78 (79 unused) */ \
+                    uint4 *pd = reinterpret_cast<uint4 *>(pp_main + 1);                               \
+                    pd[0] = make_uint4(ro.k[0], ro.k[1], ro.k[2], ro.k[3]);                           \
+                    pd[1] = make_uint4(ro.k[4], ro.k[5], ro.k[6], ro.k[7]);                           \
+                    pd[2] = make_uint4(ro.k[8], ro.k[9], ro.k[10], ro.k[11]);                         \
+                    pd[3] = make_uint4(ro.k[12], ro.k[13], ro.k[14], ro.k[15]);                       \
+                }                                                                                     \
                 pp_main += part_row_stride;                                                           \
-                pp_dep += part_row_stride;                                                            \
             }                                                                                         \
         }                                                                                             \
     }
-    uint32_t *pp_main = part + lane, *pp_dep = part + 64 + (lane & 15);      // this lane's slots in the current output row
+    uint32_t *pp_main = part + lane;      // this lane's slot in the current output row
     for (int r0 = 0; r0 < n_rows; r0 += 10) {
         SVX_ROW(0) SVX_ROW(1) SVX_ROW(2) SVX_ROW(3) SVX_ROW(4)
         SVX_ROW(5) SVX_ROW(6) SVX_ROW(7) SVX_ROW(8) SVX_ROW(9)
@@ -368,7 +364,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
                                                                  float *__restrict__ disp_all, int write_border, uint32_t *__restrict__ partial) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_stage[4][SW_SLOTS][WORDS * SW_SLOT_WORDS];
     __shared__ uint32_t lds_best[2][SW_MAX_STRIP][SW_T];
-    __shared__ __attribute__((aligned(16))) uint32_t lds_dep[4][16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave >> 1, parity = wave & 1;
@@ -402,8 +397,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
             // partial minima of this (x-block, chunk), first output row of the strip; consecutive rows are row_stride apart
             const long row_stride = (long)n_xblocks * n_chunks * SW_PART;
             uint32_t *part = BOTH ? partial + ((long)blockIdx.z * rows + y_lo) * row_stride + ((long)xblock * n_chunks + chunk) * SW_PART : nullptr;
-            if (masked) sweep_chunk<true, WORDS, MIRROR, BOTH>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best, lds_dep[wave], part, row_stride);
-            else sweep_chunk<false, WORDS, MIRROR, BOTH>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best, lds_dep[wave], part, row_stride);
+            if (masked) sweep_chunk<true, WORDS, MIRROR, BOTH>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best, part, row_stride);
+            else sweep_chunk<false, WORDS, MIRROR, BOTH>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best, part, row_stride);
         }
     }
     __syncthreads();
