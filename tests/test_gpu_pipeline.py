@@ -44,6 +44,9 @@ def run_both(ctx, left, right, params, init=0.0):
     (64, 64, 4, dict(maxDisp=16, nIters=4, gradThreshold=20, costAggrWindowSize=5)),
     (100, 200, 5, dict(maxDisp=32, nIters=2, recordFullDisp=0)),
     (48, 80, 6, dict(maxDisp=16, nIters=8, gradThreshold=10)),
+    (96, 160, 7, dict(maxDisp=32, nIters=0)),                          # no iteration: only the support points reach the map
+    (64, 48, 8, dict(maxDisp=100, nIters=2, gradThreshold=20)),        # disparity range wider than the image
+    (33, 47, 9, dict(maxDisp=16, nIters=2, gradThreshold=20)),         # crops to 32 x 32
 ])
 def test_pipeline_matches_oracle(ctx, rows, cols, seed, over):
     import stereovision_amd as S
