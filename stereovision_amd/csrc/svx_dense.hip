@@ -368,16 +368,23 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave >> 1, parity = wave & 1;
     const long n = (long)rows * cols;
-    const uint32_t *cl = cl_all + (long)blockIdx.z * n * WORDS;
-    const uint32_t *cr = cr_all + (long)blockIdx.z * n * WORDS;
-    float *disp = disp_all + (long)blockIdx.z * n;
-    const int xblock = blockIdx.x * 2 + pair;
+    // Workgroups are handed to the eight XCDs (each with its own L2) round-robin in linear order: give every XCD a
+    // contiguous run of work items (x-block pair fastest, then strip, then frame) so that the blocks that re-read the same
+    // census rows share an L2.  Placement only affects speed; any mapping is correct.
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    unsigned w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((total & 7u) == 0u) w = (w & 7u) * (total >> 3) + (w >> 3);
+    const unsigned bx = w % gridDim.x, by = (w / gridDim.x) % gridDim.y, bz = w / (gridDim.x * gridDim.y);
+    const uint32_t *cl = cl_all + (long)bz * n * WORDS;
+    const uint32_t *cr = cr_all + (long)bz * n * WORDS;
+    float *disp = disp_all + (long)bz * n;
+    const int xblock = (int)bx * 2 + pair;
     const bool active = xblock < n_xblocks;
     const int xb = min(2 + xblock * SW_T, cols - 2 - SW_T);    // first output column of this wavefront
     // strip k produces output rows [2 + k*strip_rows, 2 + (k+1)*strip_rows) clipped to rows-2; for the
     // frame border the first strip also owns rows 0,1 and the last one rows rows-2, rows-1
-    const int y_lo = 2 + blockIdx.y * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
-    const int ys = blockIdx.y == 0 ? 0 : y_lo, y_end = blockIdx.y == gridDim.y - 1 ? rows : y_hi;
+    const int y_lo = 2 + (int)by * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
+    const int ys = by == 0 ? 0 : y_lo, y_end = by == gridDim.y - 1 ? rows : y_hi;
     uint32_t (*stage)[WORDS * SW_SLOT_WORDS] = lds_stage[wave];
     uint32_t (*best)[SW_T] = lds_best[pair];
     const int n_out = y_hi - y_lo;                          // >= 1 by construction of the grid
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void dense_wta5x5_sweep_kernel
             const bool masked = (dbase + 63 > xb - 5) || (dbase + 63 > max_disp - 1) || (BOTH && xb + SW_T - 1 > cols - 6);
             // partial minima of this (x-block, chunk), first output row of the strip; consecutive rows are row_stride apart
             const long row_stride = (long)n_xblocks * n_chunks * SW_PART;
-            uint32_t *part = BOTH ? partial + ((long)blockIdx.z * rows + y_lo) * row_stride + ((long)xblock * n_chunks + chunk) * SW_PART : nullptr;
+            uint32_t *part = BOTH ? partial + ((long)bz * rows + y_lo) * row_stride + ((long)xblock * n_chunks + chunk) * SW_PART : nullptr;
             if (masked) sweep_chunk<true, WORDS, MIRROR, BOTH>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best, part, row_stride);
             else sweep_chunk<false, WORDS, MIRROR, BOTH>(cl, cr, cols, max_disp, xb, y_lo, n_rows, chunk, lane, stage, best, part, row_stride);
         }
