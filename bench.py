@@ -264,10 +264,10 @@ def main():
         # ---- dominant-kernel timing with events on the stream the kernels run on ----
         stream = torch.cuda.current_stream(dev)
         n_k = max(5, min(args.steps, 20))
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
         two_sweeps = os.environ.get("SVX_LR_TWO_SWEEPS", "0") == "1"
         both_views = lr and not two_sweeps
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
         timed = S.dominant_kernel_timer(ctx, left, right, D, disp, words, both_views=both_views)
         timed()                                   # warm
         e0.record(stream)
@@ -277,7 +277,10 @@ def main():
         e1.synchronize()
         k_ms = e0.elapsed_time(e1) / n_k
         valu_ops = 2.0 * words * pixdisp_per_frame * F              # v_xor + v_bcnt per descriptor word per pix*disp
-        hbm_bytes = float(rows * cols * F * (1 + 1 + 4))            # u8 left + u8 right in, f32 disparity out
+        # the dominant kernel's own traffic: both census batches in (4 B per word), the disparity map out, and for the
+        # both-views sweep the right view's partial minima (80 words per output row, 16-column block and 64-disparity chunk)
+        part_bytes = 4.0 * 80 * F * (rows - 4) * ((cols - 4 + 15) // 16) * ((D + 63) // 64) if both_views else 0.0
+        hbm_bytes = float(rows * cols * F * (2 * 4 * words + 4)) + part_bytes
         try:
             measured_peak = ctx.probe_valu_rate(0, 4, 20000) / 1e12
         except Exception:
