@@ -310,6 +310,32 @@ int svx_dense_point_cloud(svx_ctx *ctx, const float *disparity_map, int rows, in
                           const double *q_host, float min_disparity, double max_range, double *xyz_out, int32_t *pix_xy_out,
                           int capacity, int *frame_offsets_host);
 
+/* Stereo against Kinect depth: replaces PerformanceEvaluator, highPerfStereo/PerformanceEvaluator.cpp:16-328 (constructed at
+ * highPerfStereo/highPerfStereo.cpp:792), without its text files.  raw_depth (device, [depth_rows][depth_cols] int32, values
+ * in [0, 2048), at least 640x480) is the Kinect's raw depth; pts_xy (device) the considered pixels of the rows x cols
+ * disparity_map (device); x_offset / y_offset the common ROI's origin; q_host the 4x4 Q, cam_host the Kinect's 3x3
+ * camera matrix, r_host / t_host the rotation matrix and translation from the left stereo camera to the Kinect (all
+ * row-major doubles on the host).  The distortion coefficients the reference's constructor receives never reach
+ * projectPoints there (:16-27, :109), so there are none here.  Every considered pixel is reprojected, moved to the
+ * Kinect frame and projected into the Kinect image on the device; the correspondences (pixel inside 640x480,
+ * 0 < z <= 5000 mm, Kinect depth present) come back in input order and the statistics are accumulated on the host
+ * in the reference's order (float sums, bins ascending).
+ * Host outputs: bin_mean_host / bin_sigma_host [4][2048] (x, y, z, distance error per raw depth value; NaN where a bin
+ * is empty, as Boost's accumulators give), bin_count_host [2048], totals_host [10] = mean x, y, z, distance, sigma x, y,
+ * z, distance over all correspondences, mean and sigma of the per-bin relative distance errors; *n_corr_host =
+ * nbCorrespondences.  Synchronous. */
+int svx_kinect_evaluate(svx_ctx *ctx, const int32_t *raw_depth, int depth_rows, int depth_cols, const float *disparity_map,
+                        int rows, int cols, const int32_t *pts_xy, int n_pts, int x_offset, int y_offset, const double *q_host,
+                        const double *cam_host, const double *r_host, const double *t_host, float *bin_mean_host,
+                        float *bin_sigma_host, int32_t *bin_count_host, float *totals_host, int *n_corr_host);
+
+/* Point cloud text file, the format of highPerfStereo/highPerfStereo.cpp:703-723 ("x y z r g b" per line, numbers as
+ * the default C++ stream formatting prints doubles).  Host pointers: xyz_host 3 doubles and rgb_host 3 bytes a point;
+ * rgb_host NULL writes the constant colour const_rgb (as PerformanceEvaluator.cpp:85-106 does).  Touches no device:
+ * ctx may be NULL (then no message is kept on failure). */
+int svx_write_point_cloud_txt(svx_ctx *ctx, const char *path, const double *xyz_host, const uint8_t *rgb_host, int n_pts,
+                              const uint8_t *const_rgb);
+
 /* ---- the pipeline that calls the census path end to end ----------------------
  * svx_stereo_parameters mirrors StereoParameters, highPerfStereo/highPerfStereoLib.h:35-70, field for
  * field (bool -> int, uchar/char kept).  resizeFactor, blurSize and colorMapSliding are carried but unused,

@@ -938,6 +938,111 @@ ORC_API int orc_point_cloud(const int32_t *pts_xy, int n, const float *disp, int
     return out;
 }
 
+/* Stereo against Kinect depth, highPerfStereo/PerformanceEvaluator.cpp:132-328 (called from
+ * highPerfStereo/highPerfStereo.cpp:792).  OpenCV and Boost.Accumulators are absent; their parts are
+ * restated from their documented behaviour, so parity is unpinned:
+ *  - the considered pixels become Point3f (x+xOffset, y+yOffset, disparity) and go through
+ *    cv::perspectiveTransform with Q: double arithmetic, float result (:132-147);
+ *  - the 4x4 float matrix [R|T] (the double R and T converted to float, :53-59) times (p,1) in float, summed left to
+ *    right, gives the point in the Kinect frame (:183-200);
+ *  - cv::projectPoints without distortion (the member kinectDistortion is never assigned, :16-27,:109):
+ *    X = R p + T in double, u = fx X/Z + cx, v = fy Y/Z + cy, float result.  The reference hands the rotation over as a
+ *    Rodrigues vector and OpenCV rebuilds the matrix from it; here R itself is used;
+ *  - a point counts when Rect(0,0,640,480) contains the pixel rounded to nearest even (Point2f -> Point), and
+ *    0 < z <= 5000 in the Kinect frame (:224); its Kinect partner is the 3-D point of the pixel TRUNCATED to int (:226,
+ *    :202-204), which must have z > 0 (:228); the bin is the raw depth at the ROUNDED pixel (:236-239);
+ *  - Kinect raw depth to millimetres: 1000/(raw * -0.0030711016 + 3.3309495161) as float for raw < 2047, else 0 (:176-181);
+ *    back-projection with the constants of :161-174;
+ *  - errors: stereo minus Kinect per axis in float, distance = sqrt of the sum of squares in double, as float (:231-234);
+ *  - per bin and over all bins (visited in bin order, each bin in insertion order): Boost's lazy variance on float:
+ *    sum and sum of squares accumulate in float, mean = sum / n, variance = sumsq / n - mean * mean, sigma = sqrt;
+ *    an empty set gives NaN (:258-310).  The relative error list holds mean distance error / millimetres of the bin for
+ *    every non-empty bin but 2047 (:292-294).
+ * bin_mean / bin_sigma: [4][2048] in the order x, y, z, distance; totals: mean x, y, z, distance, sigma x, y, z, distance,
+ * mean and sigma of the relative errors.  corr_bin / corr_err (4 per correspondence) list the correspondences in input
+ * order.  Returns their number, or -1 when the depth image is smaller than 640x480 or holds a value outside [0, 2048). */
+static float kinect_mm(int raw) {
+    if (raw < 2047) return (float)(1000 * (1.0 / ((double)raw * -0.0030711016 + 3.3309495161)));
+    return 0.0f;
+}
+typedef struct { float sum, sumsq; size_t n; } lazy_var;
+static void lv_add(lazy_var *a, float v) { a->sum += v; a->sumsq += v * v; a->n += 1; }
+static float lv_mean(const lazy_var *a) { return a->sum / (float)a->n; }
+static float lv_var(const lazy_var *a) { const float m = lv_mean(a); return a->sumsq / (float)a->n - m * m; }
+
+ORC_API int orc_kinect_evaluate(const int32_t *raw_depth, int depth_rows, int depth_cols, const float *disp, int cols,
+                                const int32_t *pts_xy, int n, int x_off, int y_off, const double *q, const double *cam,
+                                const double *r, const double *t, int32_t *corr_bin, float *corr_err, float *bin_mean,
+                                float *bin_sigma, int32_t *bin_count, float *totals) {
+    if (depth_rows < 480 || depth_cols < 640) return -1;
+    for (long i = 0; i < (long)depth_rows * depth_cols; ++i)
+        if (raw_depth[i] < 0 || raw_depth[i] >= 2048) return -1;
+    const double fx_d = 1.0 / 5.9421434211923247e+02, fy_d = 1.0 / 5.9104053696870778e+02;
+    const double cx_d = 3.3930780975300314e+02, cy_d = 2.4273913761751615e+02;
+    float m[12];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) m[4 * i + j] = (float)r[3 * i + j];
+        m[4 * i + 3] = (float)t[i];
+    }
+    int nc = 0;
+    for (int i = 0; i < n; ++i) {
+        const int px = pts_xy[2 * i], py = pts_xy[2 * i + 1];
+        const float fx = (float)(px + x_off), fy = (float)(py + y_off), fd = disp[(long)py * cols + px];
+        const double x = fx, y = fy, z = fd;
+        double w = x * q[12] + y * q[13] + z * q[14] + q[15];
+        float sx = 0, sy = 0, sz = 0;
+        if (fabs(w) > (double)FLT_EPSILON) {
+            w = 1. / w;
+            sx = (float)((x * q[0] + y * q[1] + z * q[2] + q[3]) * w);
+            sy = (float)((x * q[4] + y * q[5] + z * q[6] + q[7]) * w);
+            sz = (float)((x * q[8] + y * q[9] + z * q[10] + q[11]) * w);
+        }
+        /* Kinect frame, float */
+        const float kx = m[0] * sx + m[1] * sy + m[2] * sz + m[3] * 1.0f;
+        const float ky = m[4] * sx + m[5] * sy + m[6] * sz + m[7] * 1.0f;
+        const float kz = m[8] * sx + m[9] * sy + m[10] * sz + m[11] * 1.0f;
+        /* Kinect image, double */
+        const double X = r[0] * sx + r[1] * sy + r[2] * sz + t[0];
+        const double Y = r[3] * sx + r[4] * sy + r[5] * sz + t[1];
+        const double Z = r[6] * sx + r[7] * sy + r[8] * sz + t[2];
+        const double iz = Z != 0 ? 1. / Z : 1.;
+        const float u = (float)(X * iz * cam[0] + cam[2]), v = (float)(Y * iz * cam[4] + cam[5]);
+        if (!(u > -1e6f && u < 1e6f && v > -1e6f && v < 1e6f)) continue;    /* far outside the image (or NaN) */
+        const int ur = round_half_even_f(u), vr = round_half_even_f(v);
+        if (!(ur >= 0 && ur < 640 && vr >= 0 && vr < 480 && kz > 0 && kz <= 5000)) continue;
+        const int ut = (int)u, vt = (int)v;
+        const float mm = kinect_mm(raw_depth[(long)vt * depth_cols + ut]);
+        const float qx = (float)((ut - cx_d) * (double)mm * fx_d), qy = (float)((vt - cy_d) * (double)mm * fy_d), qz = mm;
+        if (!(qz > 0)) continue;
+        const float ex = kx - qx, ey = ky - qy, ez = kz - qz;
+        const float ed = (float)sqrt((double)ex * ex + (double)ey * ey + (double)ez * ez);
+        corr_bin[nc] = raw_depth[(long)vr * depth_cols + ur];
+        corr_err[4 * nc] = ex; corr_err[4 * nc + 1] = ey; corr_err[4 * nc + 2] = ez; corr_err[4 * nc + 3] = ed;
+        ++nc;
+    }
+    /* statistics: bins in order, each in insertion order */
+    int *start = (int *)calloc(2049, sizeof(int)), *order = (int *)malloc(sizeof(int) * (size_t)(nc > 0 ? nc : 1));
+    for (int i = 0; i < nc; ++i) start[corr_bin[i] + 1]++;
+    for (int b = 0; b < 2048; ++b) { bin_count[b] = start[b + 1]; start[b + 1] += start[b]; }
+    int *fill = (int *)malloc(sizeof(int) * 2048);
+    memcpy(fill, start, sizeof(int) * 2048);
+    for (int i = 0; i < nc; ++i) order[fill[corr_bin[i]]++] = i;
+    lazy_var total[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, rel = {0, 0, 0};
+    for (int b = 0; b < 2048; ++b) {
+        lazy_var acc[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int k = 0; k < 4; ++k) {
+            for (int j = start[b]; j < start[b + 1]; ++j) { lv_add(&acc[k], corr_err[4 * order[j] + k]); lv_add(&total[k], corr_err[4 * order[j] + k]); }
+            bin_mean[k * 2048 + b] = lv_mean(&acc[k]);
+            bin_sigma[k * 2048 + b] = sqrtf(lv_var(&acc[k]));
+        }
+        if (b != 2047 && bin_count[b] > 0) lv_add(&rel, bin_mean[3 * 2048 + b] / kinect_mm(b));
+    }
+    for (int k = 0; k < 4; ++k) { totals[k] = lv_mean(&total[k]); totals[4 + k] = sqrtf(lv_var(&total[k])); }
+    totals[8] = lv_mean(&rel); totals[9] = sqrtf(lv_var(&rel));
+    free(start); free(order); free(fill);
+    return nc;
+}
+
 /* ------------------------------------------------------- 64-bit descriptors --
  * Build-defined generalisations for the 9x7 / left-right-check configuration.  The reference has
  * no 9x7 census and no dense left-right check (its generic census is square,

@@ -63,6 +63,8 @@ EXPORTS = {
     "svx_mesh_plane_prior": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_i)]),
     "svx_point_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_dense_point_cloud": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_double, _vp, _vp, _i, _vp]),
+    "svx_kinect_evaluate": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "svx_write_point_cloud_txt": (_i, [_vp, C.c_char_p, _vp, _vp, _i, _vp]),
     "svx_high_perf_stereo": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_pipeline_stage_times": (_i, [_vp, _vp, _i]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
@@ -584,6 +586,43 @@ class Context:
                    float(max_range), _dptr(xyz), _dptr(rgb) if rgb is not None else None, capacity, C.byref(k))
         m = min(k.value, capacity)
         return xyz[:m], (rgb[:m] if rgb is not None else None), k.value
+
+    def kinect_evaluate(self, raw_depth, disparity_map, pts_xy, q, cam, rotation, translation, roi=(0, 0)):
+        """PerformanceEvaluator: stereo points against the Kinect's raw depth.  raw_depth [rows>=480, cols>=640] int32,
+        disparity_map float32 and pts_xy [n,2] int32 on the device; q 4x4, cam 3x3, rotation 3x3, translation 3 on the
+        host.  Returns a dict: n_corr, bin_mean / bin_sigma [4, 2048] (x, y, z, distance), bin_count [2048],
+        mean / sigma [4], mean_rel / sigma_rel."""
+        t = self._torch
+        _check_dev(raw_depth, t.int32, "raw_depth"); _check_dev(disparity_map, t.float32, "disparity_map"); _check_dev(pts_xy, t.int32, "pts_xy")
+        qh = np.ascontiguousarray(q, dtype=np.float64).reshape(16)
+        kh = np.ascontiguousarray(cam, dtype=np.float64).reshape(9)
+        rh = np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
+        th = np.ascontiguousarray(translation, dtype=np.float64).reshape(3)
+        mean = np.zeros((4, 2048), np.float32); sigma = np.zeros((4, 2048), np.float32)
+        count = np.zeros(2048, np.int32); totals = np.zeros(10, np.float32)
+        n = _i(0)
+        self._call("svx_kinect_evaluate", _dptr(raw_depth), raw_depth.shape[0], raw_depth.shape[1], _dptr(disparity_map),
+                   disparity_map.shape[0], disparity_map.shape[1], _dptr(pts_xy) if pts_xy.shape[0] else None, pts_xy.shape[0],
+                   int(roi[0]), int(roi[1]), qh.ctypes.data_as(_vp), kh.ctypes.data_as(_vp), rh.ctypes.data_as(_vp),
+                   th.ctypes.data_as(_vp), mean.ctypes.data_as(_vp), sigma.ctypes.data_as(_vp), count.ctypes.data_as(_vp),
+                   totals.ctypes.data_as(_vp), C.byref(n))
+        return {"n_corr": n.value, "bin_mean": mean, "bin_sigma": sigma, "bin_count": count, "mean": totals[0:4].copy(),
+                "sigma": totals[4:8].copy(), "mean_rel": float(totals[8]), "sigma_rel": float(totals[9])}
+
+
+def write_point_cloud_txt(path, xyz, rgb=None, const_rgb=(0, 255, 0)):
+    """Writes "x y z r g b" lines as the reference's point cloud files hold them (host arrays; no device, no context)."""
+    lib = load_library()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    c = np.ascontiguousarray(const_rgb, dtype=np.uint8).reshape(3)
+    if rgb is not None:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+        if len(rgb) != len(xyz):
+            raise ValueError("xyz and rgb differ in length")
+    rc = lib.svx_write_point_cloud_txt(None, str(path).encode(), xyz.ctypes.data_as(_vp), rgb.ctypes.data_as(_vp) if rgb is not None else None,
+                                       len(xyz), c.ctypes.data_as(_vp))
+    if rc != 0:
+        raise SvxError(rc, lib.svx_strerror(rc).decode())
 
 
 def delaunay(pts_xy):

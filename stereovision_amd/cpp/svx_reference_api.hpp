@@ -516,3 +516,57 @@ inline void highPerfStereo(const MatU8 &leftImg, const MatU8 &rightImg, const St
     typedef typename PointVec::value_type P;
     for (int i = 0; i < n; ++i) highGradPoints.push_back(P(xy[2 * i], xy[2 * i + 1]));
 }
+
+// PerformanceEvaluator.h:14-85  PerformanceEvaluator(rawDepth, disparities, consideredDisparities, camMatrix, distortion,
+//                                                     perspTransform, rotation, translation, xOffset, yOffset)
+// Runs at construction, as the reference's does (PerformanceEvaluator.cpp:16-130), without its text files and console
+// output; the results the reference keeps private are readable.  `distortion` is accepted and unused: the reference never
+// stores it (its member stays empty, :16-27, :109).  Matrices are any type with rows/cols/step/data holding doubles
+// (cv::Mat_<double> or svx::Image<double>), the translation anything indexable with three doubles (cv::Vec3d, double[3]).
+class PerformanceEvaluator {
+public:
+    template <class MatI32, class MatF32, class PointVec, class MatD, class Vec3>
+    PerformanceEvaluator(const MatI32 &rawDepth, const MatF32 &disparities, const PointVec &consideredDisparities, const MatD &camMatrix,
+                         const MatD & /*distortion*/, const MatD &perspTransform, const MatD &rotation, const Vec3 &translation,
+                         int xOffset, int yOffset)
+        : distErrorMeans(2048), xErrorMeans(2048), yErrorMeans(2048), zErrorMeans(2048), distErrorSigmas(2048), xErrorSigmas(2048),
+          yErrorSigmas(2048), zErrorSigmas(2048), binCounts(2048) {
+        double q[16], k[9], r[9], t[3] = {translation[0], translation[1], translation[2]};
+        flatten(perspTransform, 4, 4, q); flatten(camMatrix, 3, 3, k); flatten(rotation, 3, 3, r);
+        svx::DeviceImage<int32_t> raw(rawDepth.rows, rawDepth.cols);
+        svx::DeviceImage<float> disp(disparities.rows, disparities.cols);
+        raw.upload(rawDepth); disp.upload(disparities);
+        const std::vector<int32_t> xy = svx::flatten_points(consideredDisparities);
+        svx::DeviceArray<int32_t> pts(xy.size());
+        pts.upload(xy.data());
+        std::vector<float> mean(4 * 2048), sigma(4 * 2048);
+        float totals[10];
+        svx::Runtime::check(svx_kinect_evaluate(svx::Runtime::ctx(), raw.d, rawDepth.rows, rawDepth.cols, disp.d, disparities.rows,
+                                                disparities.cols, xy.empty() ? nullptr : pts.d, (int)(xy.size() / 2), xOffset, yOffset, q, k, r, t,
+                                                mean.data(), sigma.data(), binCounts.data(), totals, &nbCorrespondences));
+        std::copy(mean.begin(), mean.begin() + 2048, xErrorMeans.begin());
+        std::copy(mean.begin() + 2048, mean.begin() + 4096, yErrorMeans.begin());
+        std::copy(mean.begin() + 4096, mean.begin() + 6144, zErrorMeans.begin());
+        std::copy(mean.begin() + 6144, mean.end(), distErrorMeans.begin());
+        std::copy(sigma.begin(), sigma.begin() + 2048, xErrorSigmas.begin());
+        std::copy(sigma.begin() + 2048, sigma.begin() + 4096, yErrorSigmas.begin());
+        std::copy(sigma.begin() + 4096, sigma.begin() + 6144, zErrorSigmas.begin());
+        std::copy(sigma.begin() + 6144, sigma.end(), distErrorSigmas.begin());
+        meanXError = totals[0]; meanYError = totals[1]; meanZError = totals[2]; meanDistError = totals[3];
+        sigmaXError = totals[4]; sigmaYError = totals[5]; sigmaZError = totals[6]; sigmaDistError = totals[7];
+        meanRelDistError = totals[8]; sigmaRelDistError = totals[9];
+    }
+
+    int nbCorrespondences = 0;
+    std::vector<float> distErrorMeans, xErrorMeans, yErrorMeans, zErrorMeans, distErrorSigmas, xErrorSigmas, yErrorSigmas, zErrorSigmas;
+    std::vector<int32_t> binCounts;       // correspondences per raw depth value (the sizes of the reference's per-bin error lists)
+    float meanDistError = 0, meanXError = 0, meanYError = 0, meanZError = 0, sigmaDistError = 0, sigmaXError = 0, sigmaYError = 0, sigmaZError = 0;
+    float meanRelDistError = 0, sigmaRelDistError = 0;
+
+private:
+    template <class MatD>
+    static void flatten(const MatD &m, int rows, int cols, double *out) {
+        if (m.rows != rows || m.cols != cols) throw sparsestereo::Exception("PerformanceEvaluator: matrix of the wrong size");
+        for (int i = 0; i < rows; ++i) std::memcpy(out + (size_t)i * cols, m.data + (size_t)i * m.step, sizeof(double) * cols);
+    }
+};

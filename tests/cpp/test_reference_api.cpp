@@ -155,6 +155,31 @@ int main() {
             catch (const Exception &e) { t3 = std::string(e.what()) == "Input images are empty!"; }
             CHECK(t1 && t2 && t3);
         }
+        // PerformanceEvaluator: the stereo camera stands where the Kinect stands and both see a wall at raw depth 921
+        {
+            const double fx = 5.9421434211923247e+02, cx = 3.3930780975300314e+02, cy = 2.4273913761751615e+02, base = 120.0;
+            const float mm = (float)(1000 * (1.0 / (921.0 * -0.0030711016 + 3.3309495161)));
+            svx::Image<int> raw(480, 640, 921);
+            MatF32 disp(480, 640, (float)(fx * base / mm));
+            std::vector<svx::Point> considered;
+            for (int y = 8; y < 480; y += 16)
+                for (int x = 8; x < 640; x += 16) considered.push_back(svx::Point(x, y));
+            svx::Image<double> K(3, 3, 0.0), D(1, 5, 0.0), Q(4, 4, 0.0), R(3, 3, 0.0);
+            K(0, 0) = fx; K(0, 2) = cx; K(1, 1) = 5.9104053696870778e+02; K(1, 2) = cy; K(2, 2) = 1;
+            Q(0, 0) = 1; Q(0, 3) = -cx; Q(1, 1) = 1; Q(1, 3) = -cy; Q(2, 3) = fx; Q(3, 2) = 1.0 / base;
+            R(0, 0) = R(1, 1) = R(2, 2) = 1;
+            const double T[3] = {0, 0, 0};
+            PerformanceEvaluator ev(raw, disp, considered, K, D, Q, R, T, 0, 0);
+            CHECK(ev.nbCorrespondences == (int)considered.size());
+            CHECK(ev.binCounts[921] == ev.nbCorrespondences && ev.binCounts[920] == 0);
+            CHECK(std::fabs(ev.zErrorMeans[921]) < 0.01f && std::fabs(ev.meanZError) < 0.01f);
+            CHECK(ev.zErrorMeans[920] != ev.zErrorMeans[920]);                   // empty bin: NaN, as the accumulators give
+            CHECK(std::fabs(ev.meanRelDistError - ev.distErrorMeans[921] / mm) < 1e-6f);
+            bool threw = false;
+            try { svx::Image<int> small(100, 100, 921); PerformanceEvaluator bad(small, disp, considered, K, D, Q, R, T, 0, 0); }
+            catch (const Exception &) { threw = true; }
+            CHECK(threw);
+        }
     } catch (const std::exception &e) {
         printf("exception: %s\n", e.what());
         return 2;

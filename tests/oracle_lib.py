@@ -279,6 +279,33 @@ def point_cloud(pts_xy, disp, q, roi=(0, 0), bgr=None, max_range=8000.0):
     return xyz[:n], (rgb[:n] if rgb is not None else None)
 
 
+lib.orc_kinect_evaluate.restype = C.c_int
+lib.orc_kinect_evaluate.argtypes = [_p, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]
+
+
+def kinect_evaluate(raw_depth, disp, pts_xy, q, cam, rotation, translation, roi=(0, 0)):
+    """PerformanceEvaluator restated: dict with n_corr, the correspondences (bin, err[4]) in input order, the per-bin
+    tables and the totals."""
+    raw = np.ascontiguousarray(raw_depth, dtype=np.int32)
+    disp = np.ascontiguousarray(disp, dtype=np.float32)
+    pts = np.ascontiguousarray(pts_xy, dtype=np.int32).reshape(-1, 2)
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(16)
+    cam = np.ascontiguousarray(cam, dtype=np.float64).reshape(9)
+    r = np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
+    t = np.ascontiguousarray(translation, dtype=np.float64).reshape(3)
+    n = len(pts)
+    cbin = np.zeros(max(n, 1), np.int32); cerr = np.zeros((max(n, 1), 4), np.float32)
+    mean = np.zeros((4, 2048), np.float32); sigma = np.zeros((4, 2048), np.float32)
+    count = np.zeros(2048, np.int32); totals = np.zeros(10, np.float32)
+    nc = lib.orc_kinect_evaluate(_ptr(raw), raw.shape[0], raw.shape[1], _ptr(disp), disp.shape[1], _ptr(pts), n, roi[0], roi[1],
+                                 _ptr(q), _ptr(cam), _ptr(r), _ptr(t), _ptr(cbin), _ptr(cerr), _ptr(mean), _ptr(sigma), _ptr(count),
+                                 _ptr(totals))
+    if nc < 0:
+        raise ValueError("raw depth image too small or out of range")
+    return {"n_corr": nc, "corr_bin": cbin[:nc], "corr_err": cerr[:nc], "bin_mean": mean, "bin_sigma": sigma, "bin_count": count,
+            "mean": totals[0:4].copy(), "sigma": totals[4:8].copy(), "mean_rel": float(totals[8]), "sigma_rel": float(totals[9])}
+
+
 # ---- 64-bit descriptors, right view, left-right check ----
 def census9x7(img):
     img = np.ascontiguousarray(img, dtype=np.uint8)

@@ -280,3 +280,40 @@ def test_dense_point_cloud(ctx, frames, rows, cols):
             assert np.all(np.diff(key) > 0)
     xyz, pix, off = ctx.dense_point_cloud(dev(disp), Q_KITTI, capacity=3)
     assert len(xyz) == min(3, int(off[-1])) and pix is None
+
+
+# ------------------------------------------------------------------ stereo against Kinect depth
+@pytest.mark.parametrize("rows,cols,n,depth_shape,seed", [(368, 1232, 120000, (480, 640), 1), (200, 300, 1025, (500, 700), 2),
+                                                           (64, 80, 1, (480, 640), 3), (64, 80, 4000, (480, 640), 4)])
+def test_kinect_evaluate(ctx, rows, cols, n, depth_shape, seed):
+    """Correspondences, per-bin tables and totals identical to the oracle's: the per-point arithmetic is the same
+    expression sequence in double/float on both sides (no contraction), the statistics the same sequential float sums."""
+    import kinect_scene as K
+    raw, disp, pts, q, cam, r, t = K.random_scene(rows, cols, n, seed, depth_shape)
+    for roi in ((0, 0), (11, 4)):
+        want = O.kinect_evaluate(raw, disp, pts, q, cam, r, t, roi)
+        got = ctx.kinect_evaluate(dev(raw), dev(disp), dev(pts), q, cam, r, t, roi)
+        assert got["n_corr"] == want["n_corr"]
+        assert np.array_equal(got["bin_count"], want["bin_count"])
+        for key in ("bin_mean", "bin_sigma", "mean", "sigma"):
+            assert np.array_equal(got[key], want[key], equal_nan=True), key
+        assert np.array_equal(np.float32([got["mean_rel"], got["sigma_rel"]]), np.float32([want["mean_rel"], want["sigma_rel"]]), equal_nan=True)
+    if n > 1000:
+        assert want["n_corr"] > 100
+
+
+def test_kinect_evaluate_consistent_scene_and_errors(ctx):
+    import stereovision_amd as S
+    import kinect_scene as K
+    raw, disp, pts, q, cam, r, t = K.consistent_scene()
+    want = O.kinect_evaluate(raw, disp, pts, q, cam, r, t)
+    got = ctx.kinect_evaluate(dev(raw), dev(disp), dev(pts), q, cam, r, t)
+    assert got["n_corr"] == want["n_corr"] == len(pts)
+    assert np.array_equal(got["mean"], want["mean"]) and np.array_equal(got["sigma"], want["sigma"])
+    # no points: every statistic is NaN, as the accumulators give for an empty set
+    none = ctx.kinect_evaluate(dev(raw), dev(disp), dev(pts[:0]), q, cam, r, t)
+    assert none["n_corr"] == 0 and np.isnan(none["mean"]).all() and np.isnan(none["bin_mean"]).all()
+    bad = raw.copy(); bad[5, 5] = 2048
+    for broken_raw, broken_pts in ((bad, pts), (raw[:400], pts), (raw, np.array([[640, 0]], np.int32))):
+        with pytest.raises(S.SvxError):
+            ctx.kinect_evaluate(dev(broken_raw), dev(disp), dev(broken_pts), q, cam, r, t)
