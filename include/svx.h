@@ -310,6 +310,12 @@ int svx_dense_point_cloud(svx_ctx *ctx, const float *disparity_map, int rows, in
                           const double *q_host, float min_disparity, double max_range, double *xyz_out, int32_t *pix_xy_out,
                           int capacity, int *frame_offsets_host);
 
+/* Replaces SparseMatch::projectMatches, sparsestereo/sparsematch.h:35-50: xyd (device) holds rectLeft.x, rectLeft.y and
+ * disparity() of every match, q_host the 4x4 Q (doubles, converted to float as the reference does); xyz_out (device)
+ * receives the three float coordinates Q.(x, y, d, 1) / w per match, with no test for w == 0, like the reference.
+ * Enqueued on the context's stream. */
+int svx_project_matches(svx_ctx *ctx, const float *xyd, int n, const double *q_host, float *xyz_out);
+
 /* Stereo against Kinect depth: replaces PerformanceEvaluator, highPerfStereo/PerformanceEvaluator.cpp:16-328 (constructed at
  * highPerfStereo/highPerfStereo.cpp:792), without its text files.  raw_depth (device, [depth_rows][depth_cols] int32, values
  * in [0, 2048), at least 640x480) is the Kinect's raw depth; pts_xy (device) the considered pixels of the rows x cols

@@ -938,6 +938,20 @@ ORC_API int orc_point_cloud(const int32_t *pts_xy, int n, const float *disp, int
     return out;
 }
 
+/* SparseMatch::projectMatches, sparsestereo/sparsematch.h:35-50: Q converted to float, the 4x4 by 4x1 float product of
+ * (rectLeft.x, rectLeft.y, disparity, 1) summed left to right in float (OpenCV's product, absent: parity unpinned), the
+ * first three components divided by the fourth with no test for zero. */
+ORC_API void orc_project_matches(const float *xyd, int n, const double *q, float *xyz) {
+    float qf[16];
+    for (int i = 0; i < 16; ++i) qf[i] = (float)q[i];
+    for (int i = 0; i < n; ++i) {
+        const float v[4] = {xyd[3 * i], xyd[3 * i + 1], xyd[3 * i + 2], 1.0f};
+        float p[4];
+        for (int r = 0; r < 4; ++r) p[r] = qf[4 * r] * v[0] + qf[4 * r + 1] * v[1] + qf[4 * r + 2] * v[2] + qf[4 * r + 3] * v[3];
+        xyz[3 * i] = p[0] / p[3]; xyz[3 * i + 1] = p[1] / p[3]; xyz[3 * i + 2] = p[2] / p[3];
+    }
+}
+
 /* Stereo against Kinect depth, highPerfStereo/PerformanceEvaluator.cpp:132-328 (called from
  * highPerfStereo/highPerfStereo.cpp:792).  OpenCV and Boost.Accumulators are absent; their parts are
  * restated from their documented behaviour, so parity is unpinned:

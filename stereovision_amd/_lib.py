@@ -63,6 +63,7 @@ EXPORTS = {
     "svx_mesh_plane_prior": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_i)]),
     "svx_point_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_dense_point_cloud": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_double, _vp, _vp, _i, _vp]),
+    "svx_project_matches": (_i, [_vp, _vp, _i, _vp, _vp]),
     "svx_kinect_evaluate": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svx_write_point_cloud_txt": (_i, [_vp, C.c_char_p, _vp, _vp, _i, _vp]),
     "svx_high_perf_stereo": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
@@ -586,6 +587,16 @@ class Context:
                    float(max_range), _dptr(xyz), _dptr(rgb) if rgb is not None else None, capacity, C.byref(k))
         m = min(k.value, capacity)
         return xyz[:m], (rgb[:m] if rgb is not None else None), k.value
+
+    def project_matches(self, xyd, q):
+        """SparseMatch::projectMatches: xyd [n,3] float32 (x, y, disparity) on the device -> [n,3] float32 points."""
+        t = self._torch
+        _check_dev(xyd, t.float32, "xyd")
+        qh = np.ascontiguousarray(q, dtype=np.float64).reshape(16)
+        out = t.empty((xyd.shape[0], 3), dtype=t.float32, device=xyd.device)
+        self._call("svx_project_matches", _dptr(xyd) if xyd.shape[0] else None, xyd.shape[0], qh.ctypes.data_as(_vp),
+                   _dptr(out) if xyd.shape[0] else None)
+        return out
 
     def kinect_evaluate(self, raw_depth, disparity_map, pts_xy, q, cam, rotation, translation, roi=(0, 0)):
         """PerformanceEvaluator: stereo points against the Kinect's raw depth.  raw_depth [rows>=480, cols>=640] int32,

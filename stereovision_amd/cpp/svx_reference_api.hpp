@@ -44,6 +44,7 @@ struct Image {
 
 struct Point { int x = 0, y = 0; Point() {} Point(int x_, int y_) : x(x_), y(y_) {} };
 struct Point2f { float x = 0, y = 0; Point2f() {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
+struct Point3f { float x = 0, y = 0, z = 0; Point3f() {} Point3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {} };
 struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; KeyPoint() {} KeyPoint(float x, float y) : pt(x, y) {} };
 
 }  // namespace svx
@@ -218,6 +219,32 @@ struct SparseMatch {
     SparseMatch(const svx::KeyPoint *l, const svx::KeyPoint *r, const svx::Point2f &rl, const svx::Point2f &rr, short c = 0)
         : imgLeft(l), imgRight(r), rectLeft(rl), rectRight(rr), cost(c) {}
     float disparity() const { return rectLeft.x - rectRight.x; }
+
+    // sparsestereo/sparsematch.h:35-50  projectMatches(matches, points, rect).  The reference takes Q from the
+    // rectification's calibration; rectification is outside this path, so Q is passed itself (any 4x4 matrix of doubles
+    // with rows/cols/step/data); the reference's signature stays for rect == NULL and throws as the reference does.
+    template <class Point3Vec, class MatD>
+    static void projectMatches(const std::vector<SparseMatch> &matches, Point3Vec *points, const MatD &Q) {
+        if (Q.rows != 4 || Q.cols != 4) throw Exception("projectMatches: Q must be 4x4");
+        double q[16];
+        for (int i = 0; i < 4; ++i) std::memcpy(q + 4 * i, Q.data + (size_t)i * Q.step, sizeof(double) * 4);
+        std::vector<float> xyd(3 * matches.size()), xyz(3 * matches.size());
+        for (size_t i = 0; i < matches.size(); ++i) {
+            xyd[3 * i] = matches[i].rectLeft.x; xyd[3 * i + 1] = matches[i].rectLeft.y; xyd[3 * i + 2] = matches[i].disparity();
+        }
+        svx::DeviceArray<float> din(xyd.size()), dout(xyz.size());
+        din.upload(xyd.data());
+        svx::Runtime::check(svx_project_matches(svx::Runtime::ctx(), din.d, (int)matches.size(), q, dout.d));
+        dout.download(xyz.data());
+        typedef typename Point3Vec::value_type P3;
+        points->reserve(points->size() + matches.size());
+        for (size_t i = 0; i < matches.size(); ++i) points->push_back(P3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+    }
+    template <class Point3Vec>
+    static void projectMatches(const std::vector<SparseMatch> &, Point3Vec *, const class StereoRectification *rect) {
+        if (rect == 0) throw Exception("Projection of 3d points is only possible for calibrated cameras.");
+        throw Exception("libsvx: projectMatches takes Q itself (rectification is outside the accelerated path)");
+    }
 };
 
 class StereoRectification;   // rectification maps are outside the accelerated path: only rect == NULL is supported

@@ -186,6 +186,17 @@ struct LazyVariance {
     float variance() const { const float m = mean(); return sumsq / (float)n - m * m; }
 };
 
+// SparseMatch::projectMatches, sparsestereo/sparsematch.h:35-50: float Q times (x, y, disparity, 1), divided by w.
+struct QMatF { float m[16]; };
+__global__ void project_matches_kernel(QMatF q, const float *__restrict__ xyd, int n, float *__restrict__ xyz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyd[3 * i], y = xyd[3 * i + 1], d = xyd[3 * i + 2];
+    float p[4];
+    for (int r = 0; r < 4; ++r) p[r] = q.m[4 * r] * x + q.m[4 * r + 1] * y + q.m[4 * r + 2] * d + q.m[4 * r + 3] * 1.0f;
+    xyz[3 * i] = p[0] / p[3]; xyz[3 * i + 1] = p[1] / p[3]; xyz[3 * i + 2] = p[2] / p[3];
+}
+
 __global__ void cloud_check_points_kernel(const int32_t *__restrict__ pts, int n, int rows, int cols, int roi_x, int roi_y,
                                           int img_rows, int img_cols, int check_img, unsigned *__restrict__ bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,5 +381,18 @@ SVX_API int svx_write_point_cloud_txt(svx_ctx *ctx, const char *path, const doub
     }
     out.close();
     if (!out) return svx_fail(ctx, SVX_ERR_INVALID_ARG, "svx_write_point_cloud_txt: write to %s failed", path);
+    return SVX_OK;
+}
+
+SVX_API int svx_project_matches(svx_ctx *ctx, const float *xyd, int n, const double *q_host, float *xyz_out) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, n >= 0 && q_host, SVX_ERR_INVALID_ARG, "svx_project_matches: bad count or null matrix");
+    if (n == 0) return SVX_OK;
+    SVX_REQUIRE(ctx, xyd && xyz_out, SVX_ERR_INVALID_ARG, "svx_project_matches: null pointer");
+    QMatF q;
+    for (int i = 0; i < 16; ++i) q.m[i] = (float)q_host[i];
+    project_matches_kernel<<<svx_cdiv(n, 256), 256, 0, ctx->stream>>>(q, xyd, n, xyz_out);
+    SVX_LAUNCH_CHECK(ctx, "project_matches_kernel");
     return SVX_OK;
 }

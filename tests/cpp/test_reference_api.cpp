@@ -155,6 +155,25 @@ int main() {
             catch (const Exception &e) { t3 = std::string(e.what()) == "Input images are empty!"; }
             CHECK(t1 && t2 && t3);
         }
+        // SparseMatch::projectMatches with Q given: (x - cx, y - cy, f) * base / d
+        {
+            std::vector<svx::KeyPoint> kl(2), kr(2);
+            kl[0] = svx::KeyPoint(100.f, 50.f); kr[0] = svx::KeyPoint(90.f, 50.f);
+            kl[1] = svx::KeyPoint(20.f, 30.f);  kr[1] = svx::KeyPoint(16.f, 30.f);
+            std::vector<SparseMatch> ms;
+            for (int i = 0; i < 2; ++i) ms.push_back(SparseMatch(&kl[i], &kr[i], kl[i].pt, kr[i].pt, 3));
+            svx::Image<double> Q(4, 4, 0.0);
+            Q(0, 0) = 1; Q(0, 3) = -64; Q(1, 1) = 1; Q(1, 3) = -32; Q(2, 3) = 500; Q(3, 2) = 0.125;
+            std::vector<svx::Point3f> pts;
+            SparseMatch::projectMatches(ms, &pts, Q);
+            CHECK(pts.size() == 2);
+            CHECK(pts[0].x == 36.f / 1.25f && pts[0].y == 18.f / 1.25f && pts[0].z == 500.f / 1.25f);
+            CHECK(pts[1].x == -44.f / 0.5f && pts[1].y == -2.f / 0.5f && pts[1].z == 1000.f);
+            bool threw = false;
+            try { SparseMatch::projectMatches(ms, &pts, (const StereoRectification *)0); }
+            catch (const Exception &e) { threw = std::string(e.what()) == "Projection of 3d points is only possible for calibrated cameras."; }
+            CHECK(threw);
+        }
         // PerformanceEvaluator: the stereo camera stands where the Kinect stands and both see a wall at raw depth 921
         {
             const double fx = 5.9421434211923247e+02, cx = 3.3930780975300314e+02, cy = 2.4273913761751615e+02, base = 120.0;

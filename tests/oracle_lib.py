@@ -279,6 +279,18 @@ def point_cloud(pts_xy, disp, q, roi=(0, 0), bgr=None, max_range=8000.0):
     return xyz[:n], (rgb[:n] if rgb is not None else None)
 
 
+lib.orc_project_matches.restype = None
+lib.orc_project_matches.argtypes = [_p, C.c_int, _p, _p]
+
+
+def project_matches(xyd, q):
+    xyd = np.ascontiguousarray(xyd, dtype=np.float32).reshape(-1, 3)
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(16)
+    out = np.zeros((max(len(xyd), 1), 3), np.float32)
+    lib.orc_project_matches(_ptr(xyd), len(xyd), _ptr(q), _ptr(out))
+    return out[:len(xyd)]
+
+
 lib.orc_kinect_evaluate.restype = C.c_int
 lib.orc_kinect_evaluate.argtypes = [_p, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]
 

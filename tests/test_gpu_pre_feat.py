@@ -317,3 +317,16 @@ def test_kinect_evaluate_consistent_scene_and_errors(ctx):
     for broken_raw, broken_pts in ((bad, pts), (raw[:400], pts), (raw, np.array([[640, 0]], np.int32))):
         with pytest.raises(S.SvxError):
             ctx.kinect_evaluate(dev(broken_raw), dev(disp), dev(broken_pts), q, cam, r, t)
+
+
+@pytest.mark.parametrize("n", [0, 1, 255, 5000])
+def test_project_matches(ctx, n):
+    """SparseMatch::projectMatches: float Q, float products summed left to right, division by w without a zero test."""
+    rng = np.random.default_rng(n)
+    xyd = np.stack([rng.integers(0, 1242, n), rng.integers(0, 375, n), rng.integers(0, 128, n)], 1).astype(np.float32)
+    for q in (Q_KITTI, rng.normal(size=(4, 4))):
+        want = O.project_matches(xyd, q)
+        got = ctx.project_matches(dev(xyd) if n else torch.empty((0, 3), dtype=torch.float32, device="cuda"), q).cpu().numpy()
+        assert np.array_equal(got, want, equal_nan=True)
+    if n:
+        assert not np.isfinite(O.project_matches(xyd[xyd[:, 2] == 0][:1], Q_KITTI)).all() or not (xyd[:, 2] == 0).any()

@@ -76,6 +76,45 @@ def test_delaunay_matches_qhull_in_general_position():
         assert canon(tri) == canon(ref)
 
 
+def _reference_triangle():
+    """The Delaunay triangulator inside the reference's libelas copy (elas/triangle.cpp), compiled from where it lies into
+    oracle/_ref by oracle/Makefile and called as elas/elas.cpp:445-494 calls it."""
+    import ctypes as C
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libref_triangle.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    lib = C.CDLL(so)
+    lib.ref_triangle_delaunay.restype = C.c_int
+    lib.ref_triangle_delaunay.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+
+    def run(pts):
+        xy = np.ascontiguousarray(pts, dtype=np.float32)
+        out = np.zeros((2 * len(pts) + 8, 3), np.int32)
+        n = lib.ref_triangle_delaunay(xy.ctypes.data, len(xy), out.ctypes.data, len(out))
+        assert 0 <= n <= len(out)
+        return out[:n]
+    return run
+
+
+def test_delaunay_against_the_reference_triangulator():
+    """In general position the triangulation is unique: the same triangles as the reference's own triangulator.  With
+    cocircular points (image-sized integer coordinates) the diagonals may differ, but the reference's result passes the
+    same checker and has the same number of triangles."""
+    ref = _reference_triangle()
+    rng = np.random.default_rng(21)
+    for n in (10, 300, 2000):
+        pts = np.unique(random_points(rng, n, 1 << 20, 1 << 20), axis=0)
+        assert canon(S.delaunay(pts)) == canon(ref(pts))
+    for n, w, h in ((500, 1242, 375), (5000, 1242, 375), (300, 40, 30)):
+        pts = np.unique(random_points(rng, n, w, h), axis=0)
+        mine, theirs = S.delaunay(pts), ref(pts)
+        assert O.delaunay_check(pts, theirs) == 0
+        assert len(mine) == len(theirs)
+        shared = len(set(canon(mine)) & set(canon(theirs)))
+        assert shared >= 0.75 * len(mine)                                      # the rest are cocircular quadruples cut the other way
+
+
 def test_checker_rejects_wrong_meshes():
     pts = np.array([[0, 0], [10, 0], [10, 10], [0, 10], [3, 4]], np.int32)
     good = S.delaunay(pts)
