@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--variant", choices=["9x7lr", "9x7", "5x5"], default="9x7lr")
     ap.add_argument("--lr-threshold", type=float, default=1.0)
+    ap.add_argument("--size", default=None, help="WxH: run frames of exactly this size instead of the default workload "
+                                                 "(1242x375 = the uncropped frame, borders as zeros; 1920x1072 and 3840x2160 = the larger configurations)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend; gloo with --one-device rehearses the multi-rank path on a one-GPU box")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -206,6 +208,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     cols, rows, D, F = 16 * (FULL_W // 16), 16 * (FULL_H // 16), args.max_disp, args.frames
+    if args.size:
+        cols, rows = (int(v) for v in args.size.lower().split("x"))
     ctx = S.Context(local_rank)
 
     # synthetic batch of this rank: frames rank*F .. rank*F+F-1 (8 distinct pairs, tiled, keeps set-up short)
@@ -349,8 +353,9 @@ def main():
             same = bool(np.array_equal(got[2:2 + nrows], want[2:2 + nrows]))
             parity = "bit-exact vs oracle on frame 0 rows 2..%d" % (1 + nrows) if same else "MISMATCH vs oracle on frame 0"
         out = {
-            "metric": "Mpix*disp/s, dense census %s + Hamming WTA%s, 1242x375 (cropped 1232x368) @%d disp"
-                      % ("5x5" if variant == "5x5" else "9x7", " + L-R check" if lr else "", D),
+            "metric": "Mpix*disp/s, dense census %s + Hamming WTA%s, %s @%d disp"
+                      % ("5x5" if variant == "5x5" else "9x7", " + L-R check" if lr else "",
+                         "%dx%d" % (cols, rows) if args.size else "1242x375 (cropped 1232x368)", D),
             "value": round(value, 1),
             "unit": "Mpix*disp/s",
             "n_gpus": world,
@@ -363,11 +368,11 @@ def main():
             "dtype": "u32" if words == 1 else "u64",
             "data": "synthetic",
             "frames_per_s": round(frames_per_s, 1),
-            "config": {"workload": "configs[1] %s, %dx%d (1242x375 cropped to /16), D=%d, %d frames/GPU/step, frame-sharded, no collective"
-                                   % ({"5x5": "reference-pinned variant: fused u8->census5x5(24-bit)->5x5-aggregated Hamming WTA",
+            "config": {"workload": "%s %s, %dx%d%s, D=%d, %d frames/GPU/step, frame-sharded, no collective"
+                                   % ("custom size:" if args.size else "configs[1]", {"5x5": "reference-pinned variant: fused u8->census5x5(24-bit)->5x5-aggregated Hamming WTA",
                                        "9x7": "without the check: fused u8->census9x7(64-bit)->5x5-aggregated Hamming WTA",
                                        "9x7lr": "fused u8->census9x7(64-bit)->5x5-aggregated Hamming WTA in both views->left-right check"}[variant],
-                                      cols, rows, D, F),
+                                      cols, rows, "" if args.size else " (1242x375 cropped to /16)", D, F),
                        "variant": variant,
                        "frames_per_gpu": F, "rows": rows, "cols": cols, "max_disp": D,
                        "parallelism": "frames x%d" % world},

@@ -598,14 +598,18 @@ __global__ __launch_bounds__(256) void census9x7_pixel_kernel(const uint8_t *__r
     }
 }
 
-// Fast variant for cols % 4 == 0 and 4-byte aligned frames: a lane owns four adjacent pixels of four rows.
-// The image is staged as dwords (every staged dword lies wholly inside or wholly outside the frame); the twelve
-// bytes x-4..x+7 of a window row are three aligned dwords, and each descriptor bit costs one SDWA byte compare
-// plus one add-with-carry that shifts it in (generated blocks, tools/gen_census97.py).
+// Fast variant: a lane owns four adjacent pixels of four rows.  The image is staged as dwords; the twelve bytes
+// x-4..x+7 of a window row are three staged dwords, and each descriptor bit costs one SDWA byte compare plus one
+// add-with-carry that shifts it in (generated blocks, tools/gen_census97.py).
+// ALIGNED (cols % 4 == 0): every staged dword is one aligned load that lies wholly inside or wholly outside the frame.
+// Otherwise a staged dword is cut out of the two aligned dwords of the batch that hold it; bytes that belong to a
+// neighbouring row or frame land only in window positions that border pixels use, and those are written as 0.
 #include "svx_census97_px.inc"
 constexpr int C97T_W = 256, C97T_H = 16, C97T_LROW = C97T_W / 4 + 2 + 1;   // dwords per staged row (+1 pad)
 
-__global__ __launch_bounds__(256) void census9x7_tile_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, uint32_t *__restrict__ out_all) {
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void census9x7_tile_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, long total_bytes,
+                                                             uint32_t *__restrict__ out_all) {
     __shared__ uint32_t tile[(C97T_H + 6) * C97T_LROW];
     const long n = (long)rows * cols;
     const uint8_t *img = img_all + (long)blockIdx.z * n;
@@ -615,7 +619,19 @@ __global__ __launch_bounds__(256) void census9x7_tile_kernel(const uint8_t *__re
         const int r = i / C97T_LROW, k = i - r * C97T_LROW;
         const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * k;
         uint32_t v = 0u;
-        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = *reinterpret_cast<const uint32_t *>(img + (long)gy * cols + gx);
+        if (ALIGNED) {
+            if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = *reinterpret_cast<const uint32_t *>(img + (long)gy * cols + gx);
+        } else if (gy >= 0 && gy < rows && gx > -4 && gx < cols) {
+            const long a = (long)blockIdx.z * n + (long)gy * cols + gx;         // byte offset in the batch, may be negative by < 4
+            const long a0 = a & ~3L;
+            if (a0 >= 0 && a0 + 8 <= total_bytes) {
+                const uint32_t d0 = *reinterpret_cast<const uint32_t *>(img_all + a0), d1 = *reinterpret_cast<const uint32_t *>(img_all + a0 + 4);
+                v = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)(a & 3));
+            } else {                                                            // the first and last bytes of the batch
+                for (int b = 0; b < 4; ++b)
+                    if (a + b >= 0 && a + b < total_bytes) v |= (uint32_t)img_all[a + b] << (8 * b);
+            }
+        }
         tile[i] = v;
     }
     __syncthreads();
@@ -639,12 +655,25 @@ __global__ __launch_bounds__(256) void census9x7_tile_kernel(const uint8_t *__re
             C97_PX1(hi[1], lo[1], W);
             C97_PX2(hi[2], lo[2], W);
             C97_PX3(hi[3], lo[3], W);
-            if (x < 4) hi[0] = lo[0] = hi[1] = lo[1] = hi[2] = lo[2] = hi[3] = lo[3] = 0u;            // cols % 4 == 0: the border
-            if (x >= cols - 4) hi[0] = lo[0] = hi[1] = lo[1] = hi[2] = lo[2] = hi[3] = lo[3] = 0u;    // columns are whole lanes
+            if (ALIGNED) {                                                                               // the border columns
+                if (x < 4) hi[0] = lo[0] = hi[1] = lo[1] = hi[2] = lo[2] = hi[3] = lo[3] = 0u;            // are whole lanes
+                if (x >= cols - 4) hi[0] = lo[0] = hi[1] = lo[1] = hi[2] = lo[2] = hi[3] = lo[3] = 0u;
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (x + p < 4 || x + p >= cols - 4) hi[p] = lo[p] = 0u;
+            }
         }
-        uint4 *o = reinterpret_cast<uint4 *>(out + ((long)y * cols + x) * 2);
-        o[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
-        o[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+        if (ALIGNED || (((cols & 1) == 0) && x + 3 < cols)) {
+            uint4 *o = reinterpret_cast<uint4 *>(out + ((long)y * cols + x) * 2);
+            o[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+            o[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+        } else {
+            uint2 *o = reinterpret_cast<uint2 *>(out + ((long)y * cols + x) * 2);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (x + p < cols) o[p] = make_uint2(lo[p], hi[p]);
+        }
     }
 }
 
@@ -654,9 +683,14 @@ SVX_API int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census,
     SVX_REQUIRE(ctx, img && census, SVX_ERR_INVALID_ARG, "svx_census9x7_u8: null pointer");
     SVX_REQUIRE(ctx, rows > 0 && cols > 0 && n_frames > 0, SVX_ERR_EMPTY, "svx_census9x7_u8: empty image");
     SVX_REQUIRE(ctx, n_frames <= 65535 && svx_cdiv(rows, C97_H) <= 65535, SVX_ERR_UNSUPPORTED, "svx_census9x7_u8: too many frames or rows per call");
-    const bool fast = (cols % 4 == 0) && (((uintptr_t)img & 3u) == 0) && (((uintptr_t)census & 15u) == 0);
-    if (fast) {
-        census9x7_tile_kernel<<<dim3(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97T_H), n_frames), 256, 0, ctx->stream>>>(img, rows, cols, census);
+    const bool fast = (((uintptr_t)img & 3u) == 0) && (((uintptr_t)census & 15u) == 0);
+    const long total_bytes = (long)rows * cols * n_frames;
+    const dim3 tgrid(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97T_H), n_frames);
+    if (fast && cols % 4 == 0) {
+        census9x7_tile_kernel<true><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
+        SVX_LAUNCH_CHECK(ctx, "census9x7_tile_kernel");
+    } else if (fast && cols >= 9) {
+        census9x7_tile_kernel<false><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
         SVX_LAUNCH_CHECK(ctx, "census9x7_tile_kernel");
     } else {
         census9x7_pixel_kernel<<<dim3(svx_cdiv(cols, C97_W), svx_cdiv(rows, C97_H), n_frames), 256, 0, ctx->stream>>>(img, rows, cols, (uint2 *)census);
@@ -774,14 +808,38 @@ static size_t both_views_partial_words(int rows, int cols, int n_frames, int max
     const size_t n_xblocks = (cols - 4 + SW_T - 1) / SW_T, n_chunks = (max_disp + 63) >> 6;
     return (size_t)n_frames * rows * n_xblocks * n_chunks * SW_PART;
 }
+// The partial minima of a call are kept below 4 GiB: a batch whose minima would take more is swept in groups of frames
+// that share one buffer.  0 = not even one frame fits (or the size is not covered): one search per view instead.
+static int both_views_group_frames(int rows, int cols, int n_frames, int max_disp) {
+    if (!both_views_eligible(rows, cols, max_disp) || rows > 65535) return 0;
+    const size_t per_frame = both_views_partial_words(rows, cols, 1, max_disp);
+    const size_t fit = ((size_t)1 << 30) / per_frame;
+    return (int)(fit < (size_t)n_frames ? fit : (size_t)n_frames);
+}
+
+// What follows the sweep of a group of frames: the right view's disparity map, or the check of the left map against the
+// partial minima (disp_right == nullptr).
 static int launch_both_views(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp,
-                             float *disp_left, float *disp_right, uint32_t *partial) {
-    int rc = words == 1 ? launch_sweep<1, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disp_left, 1, partial)
-                        : launch_sweep<2, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disp_left, 1, partial);
-    if (rc) return rc;
+                             float *disp_left, float *disp_right, float lr_threshold, int group, uint32_t *partial, bool sweep_only = false) {
+    const size_t n = (size_t)rows * cols;
     const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
-    right_view_merge_kernel<<<dim3(svx_cdiv(cols, 256), rows, n_frames), 256, 0, ctx->stream>>>(partial, rows, cols, max_disp, n_xblocks, disp_right);
-    SVX_LAUNCH_CHECK(ctx, "right_view_merge_kernel");
+    for (int f0 = 0; f0 < n_frames; f0 += group) {
+        const int nf = n_frames - f0 < group ? n_frames - f0 : group;
+        const uint32_t *gl = cl + (size_t)f0 * n * words, *gr = cr + (size_t)f0 * n * words;
+        float *dl = disp_left + (size_t)f0 * n;
+        int rc = words == 1 ? launch_sweep<1, false>(ctx, gl, gr, rows, cols, nf, max_disp, dl, 1, partial)
+                            : launch_sweep<2, false>(ctx, gl, gr, rows, cols, nf, max_disp, dl, 1, partial);
+        if (rc) return rc;
+        if (sweep_only) continue;
+        const dim3 grid(svx_cdiv(cols, 256), rows, nf);
+        if (disp_right) {
+            right_view_merge_kernel<<<grid, 256, 0, ctx->stream>>>(partial, rows, cols, max_disp, n_xblocks, disp_right + (size_t)f0 * n);
+            SVX_LAUNCH_CHECK(ctx, "right_view_merge_kernel");
+        } else {
+            lr_check_partial_kernel<<<grid, 256, 0, ctx->stream>>>(dl, partial, rows, cols, max_disp, n_xblocks, lr_threshold, -1.0f);
+            SVX_LAUNCH_CHECK(ctx, "lr_check_partial_kernel");
+        }
+    }
     return SVX_OK;
 }
 
@@ -794,16 +852,17 @@ SVX_API int svx_dense_wta_both(svx_ctx *ctx, const uint32_t *census_left, const 
     SVX_REQUIRE(ctx, disp_right != nullptr, SVX_ERR_INVALID_ARG, "svx_dense_wta_both: null pointer");
     SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_dense_wta_both: words must be 1 or 2");
     SVX_REQUIRE(ctx, rows <= 65535, SVX_ERR_UNSUPPORTED, "svx_dense_wta_both: too many rows per call");
-    // sizes the sweep kernel does not cover, or whose partial minima would exceed 4 GiB: one search per view
-    if (!both_views_eligible(rows, cols, max_disp) || both_views_partial_words(rows, cols, n_frames, max_disp) > ((size_t)1 << 30)) {
+    // sizes the sweep kernel does not cover: one search per view
+    const int group = both_views_group_frames(rows, cols, n_frames, max_disp);
+    if (group == 0) {
         rc = launch_dense(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, words, 0);
         if (rc) return rc;
         return launch_dense(ctx, census_right, census_left, rows, cols, n_frames, max_disp, disp_right, 1, words, 1);
     }
     void *ws;
-    rc = svx_ws_reserve(ctx, both_views_partial_words(rows, cols, n_frames, max_disp) * sizeof(uint32_t), &ws);
+    rc = svx_ws_reserve(ctx, both_views_partial_words(rows, cols, group, max_disp) * sizeof(uint32_t), &ws);
     if (rc) return rc;
-    return launch_both_views(ctx, census_left, census_right, rows, cols, n_frames, words, max_disp, disp_left, disp_right, (uint32_t *)ws);
+    return launch_both_views(ctx, census_left, census_right, rows, cols, n_frames, words, max_disp, disp_left, disp_right, 0.f, group, (uint32_t *)ws);
 }
 
 // Measurement aid: launches exactly the both-views sweep kernel (left map + the right view's partial minima in the
@@ -815,14 +874,12 @@ SVX_API int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left
     rc = dense_args_ok(ctx, census_left, census_right, disp_left, rows, cols, n_frames, max_disp);
     if (rc) return rc;
     SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_probe_both_views_sweep: words must be 1 or 2");
-    SVX_REQUIRE(ctx, both_views_eligible(rows, cols, max_disp) && rows <= 65535 &&
-                     both_views_partial_words(rows, cols, n_frames, max_disp) <= ((size_t)1 << 30),
-                SVX_ERR_UNSUPPORTED, "svx_probe_both_views_sweep: size not covered by the both-views sweep");
+    const int group = both_views_group_frames(rows, cols, n_frames, max_disp);
+    SVX_REQUIRE(ctx, group > 0, SVX_ERR_UNSUPPORTED, "svx_probe_both_views_sweep: size not covered by the both-views sweep");
     void *ws;
-    rc = svx_ws_reserve(ctx, both_views_partial_words(rows, cols, n_frames, max_disp) * sizeof(uint32_t), &ws);
+    rc = svx_ws_reserve(ctx, both_views_partial_words(rows, cols, group, max_disp) * sizeof(uint32_t), &ws);
     if (rc) return rc;
-    return words == 1 ? launch_sweep<1, false>(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, (uint32_t *)ws)
-                      : launch_sweep<2, false>(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, (uint32_t *)ws);
+    return launch_both_views(ctx, census_left, census_right, rows, cols, n_frames, words, max_disp, disp_left, nullptr, 0.f, group, (uint32_t *)ws, true);
 }
 
 static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
@@ -835,10 +892,10 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     const bool lr = lr_threshold >= 0.f;
     // Tuning knob: SVX_LR_TWO_SWEEPS=1 computes the right view with a second (mirrored) sweep instead of from the first one's cost values.
     static const bool two_sweeps = [] { const char *e = getenv("SVX_LR_TWO_SWEEPS"); return e && e[0] == '1'; }();
-    // the partial minima of the one-sweep path take 80 words per (row, x-block, 64-disparity chunk): beyond 4 GiB use two sweeps
-    const bool both = lr && !two_sweeps && both_views_eligible(rows, cols, max_disp) && rows <= 65535 &&
-                      both_views_partial_words(rows, cols, n_frames, max_disp) <= ((size_t)1 << 30);
-    const size_t part_words = both ? both_views_partial_words(rows, cols, n_frames, max_disp) : 0;
+    // the partial minima of the one-sweep path take 80 words per (row, x-block, 64-disparity chunk) and frame
+    const int group = lr && !two_sweeps ? both_views_group_frames(rows, cols, n_frames, max_disp) : 0;
+    const bool both = group > 0;
+    const size_t part_words = both ? both_views_partial_words(rows, cols, group, max_disp) : 0;
     void *ws;
     rc = svx_ws_reserve(ctx, (4 * n + part_words) * sizeof(uint32_t) + (lr && !both ? n * sizeof(float) : 0), &ws);
     if (rc) return rc;
@@ -850,12 +907,8 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     if (rc) return rc;
     if (both) {
         // one sweep; the check reads the right view's partial minima directly (no right disparity map is formed)
-        rc = launch_sweep<2, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, partial);
+        rc = launch_both_views(ctx, cl, cr, rows, cols, n_frames, 2, max_disp, disparity, nullptr, lr_threshold, group, partial);
         if (rc) return rc;
-        const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
-        lr_check_partial_kernel<<<dim3(svx_cdiv(cols, 256), rows, n_frames), 256, 0, ctx->stream>>>(disparity, partial, rows, cols, max_disp,
-                                                                                                      n_xblocks, lr_threshold, -1.0f);
-        SVX_LAUNCH_CHECK(ctx, "lr_check_partial_kernel");
     } else {
         rc = launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, 2, 0);
         if (rc) return rc;

@@ -29,7 +29,8 @@ def dev_u32(a):
     return dev(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32))
 
 
-@pytest.mark.parametrize("rows,cols", [(32, 64), (7, 9), (6, 8), (37, 129), (48, 256), (50, 261), (1, 1), (16, 70)])
+@pytest.mark.parametrize("rows,cols", [(32, 64), (7, 9), (6, 8), (37, 129), (48, 256), (50, 261), (1, 1), (16, 70), (375, 1242), (19, 1023),
+                                       (40, 514), (33, 10), (8, 11)])
 def test_census9x7(ctx, rows, cols):
     rng = np.random.default_rng(rows * 100 + cols)
     imgs = rng.integers(0, 256, size=(3, rows, cols), dtype=np.uint8)
@@ -176,11 +177,13 @@ def test_subpixel_4k_512_disparities(ctx):
     assert np.array_equal(fused, refined)
 
 
-@pytest.mark.parametrize("frames,rows,cols,D,band", [(2, 1072, 1920, 256, (500, 503)), (1, 2160, 3840, 512, (1000, 1002))])
+@pytest.mark.parametrize("frames,rows,cols,D,band", [(2, 1072, 1920, 256, (500, 503)), (1, 2160, 3840, 512, (1000, 1002)),
+                                                      (4, 2160, 3840, 512, (1500, 1501))])
 def test_left_right_full_size_configs(ctx, frames, rows, cols, D, band):
     """The 1920x1080 (cropped to /16, D=256) and 3840x2160 (D=512) configurations through the fused left-right entry
     point: against the oracle on a band of rows of every frame; the pixels the check rejects are exactly those where the two
-    separately computed views disagree (whole frame, device results of the one-view searches)."""
+    separately computed views disagree (whole frame, device results of the one-view searches).  Four 4K frames need more
+    than the 4 GiB the partial minima of one sweep may take, so that batch is swept in two groups of frames."""
     import stereovision_amd as S
     from stereovision_amd import synth
     ls, rs = synth.stereo_batch(rows, cols, D, frames, seed0=40 + frames)
