@@ -277,8 +277,8 @@ int svx_exfast_detect(svx_ctx *ctx, const uint8_t *img, int rows, int cols, int 
 
 /* Support-point mesh: stands in for the Fade_2D triangulation of highPerfStereoLib.cpp:434-445
  * (insert) and :457 (getTrianglePointers).  Fade2D is a closed library outside the reference
- * tree; the mesh built here satisfies the Delaunay property exactly (integer predicates) and is
- * unique unless four points are cocircular, where the diagonal chosen may differ from Fade2D's.
+ * tree; the mesh built here satisfies the Delaunay property exactly (integer predicates); where four or more
+ * points are cocircular the diagonals follow a fixed rule on the point indices and may differ from Fade2D's.
  * svx_delaunay (host in, host out): triangles as index triples into pts_xy_host, every triple
  *   rotated to lead with its smallest index, the list sorted lexicographically; repeated
  *   positions are represented by their first index; all-collinear input gives no triangle;
@@ -287,6 +287,21 @@ int svx_exfast_detect(svx_ctx *ctx, const uint8_t *img, int rows, int cols, int 
  * svx_mesh_plane_prior: triangulation, plane table (.cpp:454-466) and interpolation loop
  *   (.cpp:532-554) in one call: host support points, device disparities, device prior. */
 int svx_delaunay(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, int32_t *tri_idx_host, int capacity, int *n_tri);
+
+/* The mesh as an object that grows, the role of the Fade_2D instance that highPerfStereo() keeps across its iterations
+ * (insert: highPerfStereoLib.cpp:434-445 and, through supportResampling, :141-175; getTrianglePointers: :457).  Host
+ * only.  svx_mesh_insert appends points to the mesh's list (indices continue across calls; a repeated position keeps its
+ * first index); the first points are triangulated at once, later ones are located in the mesh and inserted one by one.
+ * Cocircular points are resolved by a fixed rule on the indices, so svx_mesh_triangles returns exactly what svx_delaunay
+ * returns for the whole list, however the list was split over the calls.  svx_mesh_prior is svx_mesh_plane_prior on the
+ * mesh as it stands.  A mesh belongs to one host thread at a time. */
+typedef struct svx_mesh svx_mesh;
+int svx_mesh_create(svx_mesh **out);
+void svx_mesh_destroy(svx_mesh *mesh);
+int svx_mesh_insert(svx_mesh *mesh, const int32_t *pts_xy_host, int n_pts);
+int svx_mesh_counts(const svx_mesh *mesh, int *n_points, int *n_triangles);
+int svx_mesh_triangles(const svx_mesh *mesh, int32_t *tri_idx_host, int capacity, int *n_tri);
+int svx_mesh_prior(svx_ctx *ctx, const svx_mesh *mesh, const float *disparities, int rows, int cols, float *prior, int *n_tri_out);
 int svx_mesh_plane_prior(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, const float *disparities, int rows, int cols,
                          float *prior, int *n_tri_out);
 

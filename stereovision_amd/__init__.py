@@ -23,8 +23,11 @@ from ._lib import (  # noqa: F401
     DOMINANT_KERNEL,
     dominant_kernel_timer,
     delaunay,
+    Mesh,
+    write_point_cloud_txt,
     StereoParameters,
 )
 
 __all__ = ["Context", "SvxError", "lib_path", "load_library", "CENSUS_SSE24", "CENSUS_GENERIC25",
-           "CENSUS_ZERO_REST", "WINDOW_5X6", "WINDOW_5X5", "EXFAST_NONMAX", "EXFAST_THRESHOLD_ROUND_SAT", "VIEW_LEFT", "VIEW_RIGHT", "EXPORTS", "StereoParameters"]
+           "CENSUS_ZERO_REST", "WINDOW_5X6", "WINDOW_5X5", "EXFAST_NONMAX", "EXFAST_THRESHOLD_ROUND_SAT", "VIEW_LEFT", "VIEW_RIGHT", "EXPORTS", "StereoParameters",
+           "delaunay", "Mesh", "write_point_cloud_txt"]

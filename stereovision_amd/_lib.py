@@ -63,6 +63,12 @@ EXPORTS = {
     "svx_mesh_plane_prior": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_i)]),
     "svx_point_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_dense_point_cloud": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_double, _vp, _vp, _i, _vp]),
+    "svx_mesh_create": (_i, [_vp]),
+    "svx_mesh_destroy": (None, [_vp]),
+    "svx_mesh_insert": (_i, [_vp, _vp, _i]),
+    "svx_mesh_counts": (_i, [_vp, _vp, _vp]),
+    "svx_mesh_triangles": (_i, [_vp, _vp, _i, _vp]),
+    "svx_mesh_prior": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "svx_project_matches": (_i, [_vp, _vp, _i, _vp, _vp]),
     "svx_kinect_evaluate": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svx_write_point_cloud_txt": (_i, [_vp, C.c_char_p, _vp, _vp, _i, _vp]),
@@ -520,6 +526,14 @@ class Context:
                    disparities.shape[1], _dptr(prior), C.byref(n))
         return prior, n.value
 
+    def mesh_prior(self, mesh, disparities, prior):
+        """svx_mesh_plane_prior on a Mesh object as it stands.  Returns (prior, n_triangles)."""
+        t = self._torch
+        _check_dev(disparities, t.float32, "disparities"); _check_dev(prior, t.float32, "prior")
+        n = _i(0)
+        self._call("svx_mesh_prior", mesh._h, _dptr(disparities), disparities.shape[0], disparities.shape[1], _dptr(prior), C.byref(n))
+        return prior, n.value
+
     def dense_point_cloud(self, disparity_map, q, roi=(0, 0), min_disparity=0.0, max_range=8000.0, capacity=None, with_pixels=False):
         """Every pixel with disparity > min_disparity, reprojected by Q and range-filtered, frames concatenated in raster
         order.  Returns (xyz [n,3] float64 device, pix [n,2] int32 device or None, frame_offsets numpy int32 [frames+1])."""
@@ -634,6 +648,49 @@ def write_point_cloud_txt(path, xyz, rgb=None, const_rgb=(0, 255, 0)):
                                        len(xyz), c.ctypes.data_as(_vp))
     if rc != 0:
         raise SvxError(rc, lib.svx_strerror(rc).decode())
+
+
+class Mesh:
+    """Growing Delaunay mesh (host only): insert() appends points, triangles() returns the canonical index triples of
+    everything inserted so far, identical to delaunay() of the whole list."""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.svx_mesh_create(C.byref(self._h))
+        if rc != 0:
+            raise SvxError(rc, self._lib.svx_strerror(rc).decode())
+
+    def close(self):
+        if self._h:
+            self._lib.svx_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def insert(self, pts_xy):
+        pts = np.ascontiguousarray(pts_xy, dtype=np.int32).reshape(-1, 2)
+        rc = self._lib.svx_mesh_insert(self._h, pts.ctypes.data_as(_vp), len(pts))
+        if rc != 0:
+            raise SvxError(rc, self._lib.svx_strerror(rc).decode())
+
+    def counts(self):
+        a, b = _i(0), _i(0)
+        self._lib.svx_mesh_counts(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def triangles(self):
+        n_pts, n_tri = self.counts()
+        tri = np.zeros((max(n_tri, 1), 3), np.int32)
+        n = _i(0)
+        rc = self._lib.svx_mesh_triangles(self._h, tri.ctypes.data_as(_vp), len(tri), C.byref(n))
+        if rc != 0:
+            raise SvxError(rc, self._lib.svx_strerror(rc).decode())
+        return tri[:n.value].copy()
 
 
 def delaunay(pts_xy):

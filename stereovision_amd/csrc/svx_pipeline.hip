@@ -200,11 +200,22 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     SVX_HIP(ctx, hipMemsetAsync(final_costs, 25, n, ctx->stream));
 
     clk.mark(5);
+    // the mesh lives across the iterations, as the reference's Fade_2D object does: the sparse matcher's points are
+    // triangulated at once, the resampling step's points are inserted into what is there
+    struct MeshHolder {
+        svx_mesh *m = nullptr;
+        ~MeshHolder() { svx_mesh_destroy(m); }
+    } mesh;
+    size_t in_mesh = 0;                      // support points (pairs) already handed to the mesh
+    if (prm->recordFullDisp && prm->nIters > 0 && svx_mesh_create(&mesh.m) != SVX_OK) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: mesh");
     for (int iter = 1; iter <= prm->nIters; ++iter) {                                                   // .cpp:451
         // plane table and interpolation of the prior over the whole frame (.cpp:454-466, :532-554)
         if (prm->recordFullDisp) {
             int n_tri = 0;
-            SVX_TRY(svx_mesh_plane_prior(ctx, sup.data(), (int)(sup.size() / 2), disparities, R, Cc, disparities, &n_tri));
+            if (svx_mesh_insert(mesh.m, sup.data() + in_mesh, (int)((sup.size() - in_mesh) / 2)) != SVX_OK)
+                return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "svx_high_perf_stereo: mesh insertion failed");
+            in_mesh = sup.size();
+            SVX_TRY(svx_mesh_prior(ctx, mesh.m, disparities, R, Cc, disparities, &n_tri));
         }
         clk.mark(6);
         SVX_HIP(ctx, hipMemsetAsync(costs, t_high & 0xff, n, ctx->stream));                             // .cpp:573

@@ -129,3 +129,56 @@ def test_checker_rejects_wrong_meshes():
 def test_delaunay_rejects_out_of_range():
     with pytest.raises(S.SvxError):
         S.delaunay([[0, 0], [1 << 25, 3], [5, 5]])
+
+
+def _grown(pts, first, chunk):
+    m = S.Mesh()
+    m.insert(pts[:first])
+    for i in range(first, len(pts), chunk):
+        m.insert(pts[i:i + chunk])
+    tri = m.triangles()
+    assert m.counts()[0] == len(pts)
+    m.close()
+    return tri
+
+
+@pytest.mark.parametrize("n,w,h,first,chunk", [(400, 1242, 375, 300, 7), (400, 40, 30, 10, 1), (2000, 1242, 375, 1500, 100),
+                                                (300, 12, 12, 3, 5), (500, 1 << 20, 1 << 20, 50, 50), (60, 9, 2, 4, 1),
+                                                (200, 200, 1, 150, 10), (200, 30, 30, 0, 1), (100, 50, 50, 2, 1)])
+def test_mesh_grown_equals_triangulation_from_scratch(n, w, h, first, chunk):
+    """The mesh is a function of the point list alone: however the list is split over insertions (points inside
+    triangles, on edges, on and outside the hull, repeats, cocircular grids, collinear starts), the triangles are those of
+    delaunay() on the whole list."""
+    rng = np.random.default_rng(n + w + first)
+    for rep in range(3):
+        pts = random_points(rng, n, w, h)              # with repeats on the small grids
+        want = S.delaunay(pts)
+        assert O.delaunay_check(pts, want) == 0 or h == 1
+        got = _grown(pts, first, chunk)
+        assert np.array_equal(got, want)
+
+
+def test_mesh_grown_on_a_grid_and_outwards():
+    # a full grid (every square cocircular), inserted inside-out so that every later point lies outside the hull
+    ys, xs = np.mgrid[0:12, 0:17]
+    grid = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+    order = np.argsort(((grid - grid.mean(0)) ** 2).sum(1), kind="stable")
+    pts = grid[order]
+    want = S.delaunay(pts)
+    assert len(want) == 2 * 11 * 16 and O.delaunay_check(pts, want) == 0
+    for first, chunk in ((3, 1), (20, 13), (len(pts), 1)):
+        assert np.array_equal(_grown(pts, first, chunk), want)
+    # and in reverse: points inside the hull of the first ones
+    rev = pts[::-1].copy()
+    assert np.array_equal(_grown(rev, 60, 9), S.delaunay(rev))
+
+
+def test_delaunay_is_independent_of_the_order_of_construction():
+    """Same point set, ids permuted: the triangle SETS agree when the tie rule sees the same ids, i.e. the canonical
+    triangulation depends on the list, and relabelling the list relabels the result."""
+    rng = np.random.default_rng(77)
+    pts = np.unique(random_points(rng, 300, 25, 25), axis=0)
+    tri = S.delaunay(pts)
+    # rotate the picture by 90 degrees (an isometry keeps cocircularity and the ids): the same index triples
+    rot = np.stack([-pts[:, 1], pts[:, 0]], 1).astype(np.int32)
+    assert canon(S.delaunay(rot)) == canon(tri)

@@ -42,6 +42,38 @@ def main():
             OP.high_perf_stereo(pairs[0][0], pairs[0][1], p, dm, S.delaunay)
             rec["cpu_oracle_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3, 1)
         print(json.dumps(rec), flush=True)
+    ctx.close()
+    # Frames are independent: host threads with a context each (the host share of a frame, the triangulation, is what
+    # limits one thread) keep one GPU busy.  ctypes releases the interpreter lock during a call.
+    if "--threads" in sys.argv:
+        import threading
+        p = S.StereoParameters.reference_defaults(maxDisp=70, nIters=2)
+        pairs = [synth.stereo_pair(rows, cols, 64, seed)[:2] for seed in range(4)]
+        for T in (1, 2, 4, 8, 16):
+            ctxs = [S.Context(0) for _ in range(T)]
+            streams = [torch.cuda.Stream() for _ in range(T)]
+            for c, st in zip(ctxs, streams):
+                c.bind_stream(st)                                    # a stream per context: no thread waits for another's kernels
+            devs = [[(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs] for _ in range(T)]
+            outs = [torch.zeros((rows, cols), dtype=torch.float32, device="cuda") for _ in range(T)]
+            per_thread = 8
+            def work(i, n):
+                for k in range(n):
+                    l, r = devs[i][k % len(pairs)]
+                    ctxs[i].high_perf_stereo(l, r, p, outs[i])
+            for i in range(T):
+                work(i, 1)                                           # warm-up (workspace growth)
+            torch.cuda.synchronize()
+            th = [threading.Thread(target=work, args=(i, per_thread)) for i in range(T)]
+            t0 = time.perf_counter()
+            for t in th: t.start()
+            for t in th: t.join()
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t0
+            print(json.dumps({"pipeline": "svx_high_perf_stereo", "nIters": 2, "host_threads": T, "frames": T * per_thread,
+                              "frames_per_s": round(T * per_thread / secs, 1), "ms_per_frame_per_thread": round(secs / per_thread * 1e3, 2)}), flush=True)
+            for c in ctxs:
+                c.close()
 
 
 if __name__ == "__main__":
