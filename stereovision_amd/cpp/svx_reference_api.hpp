@@ -15,6 +15,7 @@
 #include <exception>
 #include <string>
 #include <type_traits>
+#include <unordered_set>
 #include <vector>
 #include "../../include/svx.h"
 
@@ -396,24 +397,34 @@ inline ConfidentSupport epipolarMatching(const MatU32 &censusLeft, const MatU32 
 
 // Support-point mesh with the two operations the pipeline needs from Fade_2D (highPerfStereoLib.cpp:434-445, :457):
 // insert a point, list the triangles.  Points are kept in insertion order without repeats; triangles() runs libsvx's
-// exact Delaunay triangulation (index triples into points()).
+// exact Delaunay triangulation (index triples into points()); every insert goes into the mesh that is there (svx_mesh_*).
 namespace svx {
 class Mesh {
 public:
+    Mesh() { if (svx_mesh_create(&m) != SVX_OK) throw sparsestereo::Exception("libsvx: cannot create a mesh"); }
+    ~Mesh() { svx_mesh_destroy(m); }
+    Mesh(const Mesh &) = delete;
+    Mesh &operator=(const Mesh &) = delete;
     void insert(const Point &p) {
-        for (size_t i = 0; i < pts.size(); ++i) if (pts[i].x == p.x && pts[i].y == p.y) return;
+        const uint64_t key = ((uint64_t)(uint32_t)p.x << 32) | (uint32_t)p.y;
+        if (!seen.insert(key).second) return;
+        const int32_t xy[2] = {p.x, p.y};
+        if (svx_mesh_insert(m, xy, 1) != SVX_OK) throw sparsestereo::Exception("libsvx: mesh point out of range");
         pts.push_back(p);
     }
     const std::vector<Point> &points() const { return pts; }
     std::vector<int32_t> triangles() const {
-        std::vector<int32_t> xy = flatten_points(pts), tri(6 * pts.size() + 3);
+        std::vector<int32_t> tri(6 * pts.size() + 3);
         int n = 0;
-        Runtime::check(svx_delaunay(Runtime::ctx(), xy.data(), (int)pts.size(), tri.data(), (int)(tri.size() / 3), &n));
+        if (svx_mesh_triangles(m, tri.data(), (int)(tri.size() / 3), &n) != SVX_OK) throw sparsestereo::Exception("libsvx: mesh");
         tri.resize(3 * (size_t)n);
         return tri;
     }
+    const svx_mesh *handle() const { return m; }
 private:
+    svx_mesh *m = nullptr;
     std::vector<Point> pts;
+    std::unordered_set<uint64_t> seen;
 };
 // How supportResampling hands a new support point to the mesh.  The default fits svx::Mesh and any type with
 // insert(svx::Point); a caller that keeps Fade2D adds, before including this header's users,
