@@ -335,10 +335,10 @@ private:
             if (n_bp1 >= 0) t[n_bp1].n[slot_of_neighbour(t[n_bp1], t1)] = t2;
             note_hull_edges(t1);
             note_hull_edges(t2);
+            // p1 is the point being inserted: everything else was legal before, and edges that end in p1 stay legal, so
+            // only the two edges now opposite p1 can have become illegal
             stack_.push_back(std::make_pair(t1, 0));
-            stack_.push_back(std::make_pair(t1, 2));
             stack_.push_back(std::make_pair(t2, 0));
-            stack_.push_back(std::make_pair(t2, 1));
         }
     }
 };
