@@ -109,7 +109,8 @@ class SvxError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libsvx.so")
+    # SVX_LIBRARY names another build of the library (A/B measurements); the default is the in-tree one
+    return os.environ.get("SVX_LIBRARY") or os.path.join(_HERE, "libsvx.so")
 
 
 _LIB = None
