@@ -443,6 +443,19 @@ __device__ __forceinline__ float right_disparity(const uint32_t *__restrict__ pr
     for (int c = 0; c < n_chunks; ++c) {
         const int dbase = c << 6;
         const int b0 = (xr + dbase - 2) >> 4;                       // block of left column xr + dbase (floor; may be -1)
+        if (xr >= 2 && b0 + 4 < n_xblocks - 1) {
+            // All five blocks are regular ones (xb = 2 + 16 b) and none of their chunks was skipped (xb + 13 >= dbase
+            // follows from xr >= 2): L = L0 + 16 k with L0 = 15 - ((xr - 2) & 15), so blocks k = 0..3 hold the diagonal
+            // in slot L and block k = 4 holds it in slot 78 - L0 unless L0 = 15.
+            const int l0 = 15 - ((xr - 2) & 15);
+            const unsigned blk = (unsigned)n_chunks * SW_PART;
+            const uint32_t *p = prow + ((unsigned)b0 * n_chunks + c) * SW_PART;
+            const uint32_t v0 = p[l0], v1 = p[blk + 16 + l0], v2 = p[2 * blk + 32 + l0], v3 = p[3 * blk + 48 + l0];
+            const uint32_t v4 = p[4 * blk + 78 - l0];               // slot 63 when l0 = 15: another diagonal, not used then
+            best = min(best, min(min(v0, v1), min(v2, v3)));
+            best = min(best, l0 == 15 ? 0xffffffffu : v4);
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int b = b0 + k;
