@@ -532,6 +532,9 @@ static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
         SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_plain_kernel");
         return SVX_OK;
     }
+    static const int use_mx = [] { const char *e = getenv("SVX_MX"); return e ? atoi(e) : 0; }();
+    if (use_mx && words == 2 && !mirror && svx_mx_sweep_eligible(rows, cols, max_disp))
+        return svx_launch_mx_sweep(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border);
     if (words == 1) return mirror ? launch_sweep<1, true>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border)
                                   : launch_sweep<1, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border);
     return mirror ? launch_sweep<2, true>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border)
