@@ -427,6 +427,12 @@ int svx_probe_valu_rate(svx_ctx *ctx, int mode, int waves_per_simd, int iters, d
  * that a benchmark can bracket it with stream events.  Asynchronous. */
 int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
                                int n_frames, int words, int max_disp, float *disp_left);
+/* The search of svx_dense_wta / svx_dense_wta_both on two-word descriptors with the cost values formed on the matrix
+ * cores (fp4 dot products of the expanded descriptors; denseCensusStereo/denseCensusStereo.cpp:87-131 generalised as
+ * there): identical results.  Covers cols >= 36, rows >= 5, 1 <= max_disp <= 128 (SVX_ERR_UNSUPPORTED otherwise).
+ * disp_right may be NULL (left view only).  Border pixels are written as 0.  Asynchronous. */
+int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
+                         int max_disp, float *disp_left, float *disp_right);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,7 @@ EXPORTS = {
     "svx_pipeline_stage_times": (_i, [_vp, _vp, _i]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
     "svx_probe_both_views_sweep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "svx_dense_wta_matrix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 
 
@@ -343,6 +344,20 @@ class Context:
         dl = t.empty(tuple(img_shape), dtype=t.float32, device=census_left.device)
         dr = t.empty(tuple(img_shape), dtype=t.float32, device=census_left.device)
         self._call("svx_dense_wta_both", _dptr(census_left), _dptr(census_right), r, c, f, int(words), int(max_disp), _dptr(dl), _dptr(dr))
+        return dl, dr
+
+    def dense_wta_matrix(self, census_left, census_right, max_disp, both=True):
+        """svx_dense_wta_matrix: two-word descriptors, the matrix-core form; (disp_left, disp_right or None)."""
+        t = self._torch
+        _check_dev(census_left, t.int32, "census_left"); _check_dev(census_right, t.int32, "census_right")
+        if census_left.shape != census_right.shape:
+            raise SvxError(-2, "Mismatching image sizes")
+        img_shape = census_left.shape[:-1]
+        f, r, c = (1,) + tuple(img_shape) if len(img_shape) == 2 else tuple(img_shape)
+        dl = t.empty(tuple(img_shape), dtype=t.float32, device=census_left.device)
+        dr = t.empty(tuple(img_shape), dtype=t.float32, device=census_left.device) if both else None
+        self._call("svx_dense_wta_matrix", _dptr(census_left), _dptr(census_right), r, c, f, int(max_disp), _dptr(dl),
+                   _dptr(dr) if both else None)
         return dl, dr
 
     def lr_check(self, disp_left, disp_right, threshold, invalid=-1.0):

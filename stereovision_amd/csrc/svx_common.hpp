@@ -54,10 +54,13 @@ int svx_ws_reserve(svx_ctx *ctx, size_t bytes, void **out);
 int svx_pinned_reserve(svx_ctx *ctx, size_t bytes, void **out);
 int svx_enter(svx_ctx *ctx);
 
-// Matrix-core form of the dense left-view search on two-word descriptors (svx_dense_mx.hip).
+// Matrix-core form of the dense search on two-word descriptors (svx_dense_mx.hip).
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp);
+size_t svx_mx_partial_words(int rows, int cols, int n_frames, int max_disp);
 int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
-                        float *disparity, int write_border);
+                        float *disparity, int write_border, float *partial);
+int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int max_disp,
+                        float *disp_left, float *disp_right, float lr_threshold);
 
 // ---- device helpers -------------------------------------------------------
 

@@ -534,7 +534,7 @@ static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     }
     static const int use_mx = [] { const char *e = getenv("SVX_MX"); return e ? atoi(e) : 0; }();
     if (use_mx && words == 2 && !mirror && svx_mx_sweep_eligible(rows, cols, max_disp))
-        return svx_launch_mx_sweep(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border);
+        return svx_launch_mx_sweep(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border, nullptr);
     if (words == 1) return mirror ? launch_sweep<1, true>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border)
                                   : launch_sweep<1, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border);
     return mirror ? launch_sweep<2, true>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border)
@@ -839,10 +839,22 @@ static int launch_both_views(svx_ctx *ctx, const uint32_t *cl, const uint32_t *c
                              float *disp_left, float *disp_right, float lr_threshold, int group, uint32_t *partial, bool sweep_only = false) {
     const size_t n = (size_t)rows * cols;
     const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
+    // Tuning knob: SVX_MX=1 forms the cost values on the matrix cores where that form applies (its partial keys take
+    // half the room of the vector sweep's partial minima, so the buffer sized for those is large enough).
+    static const int use_mx = [] { const char *e = getenv("SVX_MX"); return e ? atoi(e) : 0; }();
+    const bool mx = use_mx && words == 2 && svx_mx_sweep_eligible(rows, cols, max_disp);
     for (int f0 = 0; f0 < n_frames; f0 += group) {
         const int nf = n_frames - f0 < group ? n_frames - f0 : group;
         const uint32_t *gl = cl + (size_t)f0 * n * words, *gr = cr + (size_t)f0 * n * words;
         float *dl = disp_left + (size_t)f0 * n;
+        if (mx) {
+            int rc = svx_launch_mx_sweep(ctx, gl, gr, rows, cols, nf, max_disp, dl, 1, (float *)partial);
+            if (rc) return rc;
+            if (sweep_only) continue;
+            rc = svx_launch_mx_right(ctx, (const float *)partial, rows, cols, nf, max_disp, dl, disp_right ? disp_right + (size_t)f0 * n : nullptr, lr_threshold);
+            if (rc) return rc;
+            continue;
+        }
         int rc = words == 1 ? launch_sweep<1, false>(ctx, gl, gr, rows, cols, nf, max_disp, dl, 1, partial)
                             : launch_sweep<2, false>(ctx, gl, gr, rows, cols, nf, max_disp, dl, 1, partial);
         if (rc) return rc;

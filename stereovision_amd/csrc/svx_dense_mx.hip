@@ -13,10 +13,14 @@
 // accumulator element (key = acc * 1024 + bias, bias = 1023 - d or a large negative number), the winner of a left
 // column is the maximum key over the tiles and over the 32 lanes that hold its right columns.
 #include "svx_common.hpp"
+#include <utility>
 
 typedef int mx_v8i __attribute__((ext_vector_type(8)));
 typedef float mx_v16f __attribute__((ext_vector_type(16)));
 
+#ifndef MX_X
+#define MX_X 0      // measurement aid: bit 0 drops the staging work, bit 1 the winner selection (results are wrong then)
+#endif
 constexpr int MX_M = 32;                 // left columns per wavefront
 constexpr int MX_MAX_STRIP = 96;
 
@@ -45,116 +49,336 @@ __device__ __forceinline__ mx_v8i mx_frag(const uint4 v) {
     return f;
 }
 
-// Maximum over the 16 lanes of every row for 16 registers at once: lane l ends up with register (l & 15).
-__device__ __forceinline__ float mx_reduce16(const float (&k)[16], int lane) {
-    float r[8], q[4], u[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        // lanes 0..7 of a row (banks 0,1) keep register i, lanes 8..15 register i + 8
-        asm volatile("s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_max_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
-                     : "=&v"(r[i]) : "v"(k[i]), "v"(k[i + 8]));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        // banks 0,2 keep register i (partner lane + 4), banks 1,3 register i + 4 (partner lane - 4)
-        asm volatile("s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-                     "v_max_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
-                     : "=&v"(q[i]) : "v"(r[i]), "v"(r[i + 4]));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        asm volatile("s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                     : "=&v"(u[i]) : "v"(q[i]));
-    }
-    const float w0 = (lane & 1) ? u[1] : u[0];
-    const float w1 = (lane & 1) ? u[3] : u[2];
+// Pieces of the maximum over the 16 lanes of every row for 16 registers at once (lane l ends up with register l & 15);
+// they are issued between the matrix instructions of the following row.
+// stage A, pair i: lanes 0..7 of a row (banks 0,1) keep register i, lanes 8..15 register i + 8
+#define MX_RED_A(i) asm volatile("s_nop 1\n\t"                                                       \
+                                 "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+                                 "v_max_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"     \
+                                 : "=&v"(st.ra[i]) : "v"(st.best[i]), "v"(st.best[i + 8]))
+// stage B, pair i: banks 0,2 keep register i (partner lane + 4), banks 1,3 register i + 4 (partner lane - 4)
+#define MX_RED_B(i) asm volatile("s_nop 1\n\t"                                                       \
+                                 "v_max_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
+                                 "v_max_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"     \
+                                 : "=&v"(st.rb[i]) : "v"(st.ra[i]), "v"(st.ra[i + 4]))
+#define MX_RED_C() asm volatile("s_nop 1\n\t"                                                                  \
+                                "v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+                                "v_max_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+                                "v_max_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+                                "v_max_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"      \
+                                : "=&v"(st.rc[0]), "=&v"(st.rc[1]), "=&v"(st.rc[2]), "=&v"(st.rc[3])           \
+                                : "v"(st.rb[0]), "v"(st.rb[1]), "v"(st.rb[2]), "v"(st.rb[3]))
+
+__device__ __forceinline__ float mx_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float mx_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression in the body.
+template <int... Is, class F>
+__device__ __forceinline__ void mx_static_for(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
+
+template <int T>
+struct MxState {
+    using G = MxGeom<T>;
+    static constexpr int RR = G::RW / 64;                    // staging rounds that hold right words only
+    uint32_t wn[G::ROUNDS], wo[G::ROUNDS];                   // census words of the next row to stage (entering, leaving)
+    uint32_t roff[RR];                                       // rounds < RR: this lane's word offset in a right row
+    const uint32_t *src[G::ROUNDS - RR];                     // the other rounds: this lane's word in row 0 of the strip
+    uint32_t flip[G::ROUNDS - RR];                           // all ones where that word is a left word
+    uint32_t hx, hy;                                         // first half of the expansion under way
+    float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
+    float pen_l[T], pen_r[16];                               // border blocks: what each view must not use (0 or -2^21)
+    float *out;                                              // left map: this lane's pixel of the row being written
+    float *part;                                             // right view: this lane's slot of the row being written
+    long part_stride, out_stride;
+};
+
+// Accumulator element i of tile u as the left view (L) or the right view sees it.
+template <int T, bool EDGE>
+__device__ __forceinline__ float mx_elem_l(const mx_v16f (&acc)[T], const MxState<T> &st, int u, int i) { return EDGE ? acc[u][i] + st.pen_l[u] : acc[u][i]; }
+template <int T, bool EDGE>
+__device__ __forceinline__ float mx_elem_r(const mx_v16f (&acc)[T], const MxState<T> &st, int u, int i) { return EDGE ? acc[u][i] + st.pen_r[i] : acc[u][i]; }
+
+// Right view, tile u: the best key of each right column over the tile's 32 left columns, in three pieces.
+template <int T, bool EDGE, int U>
+__device__ __forceinline__ void mx_right_a(const mx_v16f (&acc)[T], const MxState<T> &st, float (&x)[5]) {
+    x[0] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 0), mx_elem_r<T, EDGE>(acc, st, U, 1), mx_elem_r<T, EDGE>(acc, st, U, 2));
+    x[1] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 3), mx_elem_r<T, EDGE>(acc, st, U, 4), mx_elem_r<T, EDGE>(acc, st, U, 5));
+    x[2] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 6), mx_elem_r<T, EDGE>(acc, st, U, 7), mx_elem_r<T, EDGE>(acc, st, U, 8));
+    x[3] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 9), mx_elem_r<T, EDGE>(acc, st, U, 10), mx_elem_r<T, EDGE>(acc, st, U, 11));
+}
+template <int T, bool EDGE, int U>
+__device__ __forceinline__ void mx_right_b(const mx_v16f (&acc)[T], const MxState<T> &st, float (&x)[5]) {
+    x[4] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 12), mx_elem_r<T, EDGE>(acc, st, U, 13), mx_elem_r<T, EDGE>(acc, st, U, 14));
+    x[0] = mx_max3(x[0], x[1], x[2]);
+    x[0] = mx_max3(x[0], x[3], x[4]);
+    x[0] = mx_max(x[0], mx_elem_r<T, EDGE>(acc, st, U, 15));
+}
+template <int U>
+__device__ __forceinline__ void mx_right_c(float *__restrict__ part, const float (&x)[5], int swap32) {
+    // the other half of the wavefront holds the other 16 left columns of the same right column
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(swap32, __builtin_bit_cast(int, x[0])));
+    part[U * 32] = mx_max(x[0], o);                          // lanes l and l ^ 32 write the same value to the same place
+}
+
+// Decodes the winner of a left pixel: key = window score + (1023 - d) / 1024; an inadmissible pair sits near -2^20.
+__device__ __forceinline__ float mx_decode(float z) {
+    const float frac = z - __builtin_floorf(z);
+    return z < -524288.0f ? 0.0f : 1023.0f - frac * 1024.0f;
+}
+
+template <int T>
+__device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane) {
+    const float w0 = (lane & 1) ? st.rc[1] : st.rc[0];
+    const float w1 = (lane & 1) ? st.rc[3] : st.rc[2];
     float x0, x1;
     asm volatile("s_nop 1\n\t"
                  "v_max_f32_dpp %0, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                  "v_max_f32_dpp %1, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
                  : "=&v"(x0), "=&v"(x1) : "v"(w0), "v"(w1));
-    return (lane & 2) ? x1 : x0;
+    float z = (lane & 2) ? x1 : x0;                          // lane l: register (l & 15) over its 16-lane row
+    const float zo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, z), 0x401f));   // lane ^ 16
+    *st.out = mx_decode(mx_max(z, zo));                      // lanes l and l ^ 16 write the same value to the same place
 }
 
-// One census row: stage the entering row (and the leaving one) as fp4 operands, run the products, pick the winners.
-// The staging buffers are single: LDS operations of one wavefront execute in order, so the writes of a row follow the
-// reads of the previous one.
-template <int T, bool LEAVING, bool OUTPUT>
-__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], uint4 *__restrict__ bn, uint4 *__restrict__ bo,
-                                       const uint32_t (&wn)[MxGeom<T>::ROUNDS], const uint32_t (&wo)[MxGeom<T>::ROUNDS],
-                                       uint32_t left_mask_hi, uint32_t left_mask_lo, int lane, float *__restrict__ out) {
+// One census row r.  Its operands are in `cur` (staged while the previous row ran).  Between its matrix instructions
+// the wavefront stages row r+1 into `nxt` and fetches the words of row r+2 and, in the steady state (STEADY: the row
+// five rows up leaves the window, its products with the left operand negated are added too, and every row has an
+// output), picks the winners: a tile's accumulators are final from its last product until its first product of the
+// next row, so tiles 0 .. T-2 are read while later tiles of the same row run and tile T-1 while tile 0 of the next
+// row runs, followed by the lane reduction and the store of that previous row.
+template <int T, bool STEADY, bool BOTH, bool EDGE>
+__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *__restrict__ cur_n, const uint4 *__restrict__ cur_o,
+                                       uint4 *__restrict__ nxt_n, uint4 *__restrict__ nxt_o, MxState<T> &st,
+                                       const uint32_t *__restrict__ right_new, const uint32_t *__restrict__ right_old,
+                                       long off_new, long off_old, int lane, int swap32) {
     using G = MxGeom<T>;
+    constexpr int PER = STEADY ? 10 : 5, S = T * PER, P = 4, RR = MxState<T>::RR;
+    constexpr int UNITS = STEADY ? 4 * G::ROUNDS : 2 * G::ROUNDS;     // staging work in halves of a round, or whole rounds
+    static_assert(S >= UNITS, "one unit of staging work per matrix instruction at most");
+    static_assert(T >= 3, "the fold schedule needs three tiles");
     const int n = lane & 31, h = lane >> 5;
     uint32_t c22;
     asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
-#pragma unroll
-    for (int i = 0; i < G::ROUNDS; ++i) bn[i * 64 + lane] = mx_expand(wn[i], c22);
-    if (LEAVING) {
-        // the leaving row's left words are complemented: its products are subtracted
-#pragma unroll
-        for (int i = 0; i < G::ROUNDS; ++i) {
-            const uint32_t flip = i == G::ROUNDS - 1 ? left_mask_hi : (i == G::ROUNDS - 2 ? left_mask_lo : 0u);
-            bo[i * 64 + lane] = mx_expand(wo[i] ^ flip, c22);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
+    const uint32_t m88 = 0x88888888u;
     mx_v8i an[5], ao[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        an[k] = mx_frag(bn[G::RW + (n + k) * 2 + h]);
-        if (LEAVING) ao[k] = mx_frag(bo[G::RW + (n + k) * 2 + h]);
+        an[k] = mx_frag(cur_n[G::RW + (n + k) * 2 + h]);
+        if (STEADY) ao[k] = mx_frag(cur_o[G::RW + (n + k) * 2 + h]);
     }
-    // T * PER products; the right operand of product s + P is fetched before product s is issued
-    constexpr int PER = LEAVING ? 10 : 5, S = T * PER, P = 4;
     auto right = [&](int s) -> uint4 {
         const int t = s / PER, j = s % PER, k = j % 5;
-        return (j >= 5 ? bo : bn)[(32 * t + n + k) * 2 + h];
+        return (j >= 5 ? cur_o : cur_n)[(32 * t + n + k) * 2 + h];
     };
     uint4 fb[P];
 #pragma unroll
     for (int s = 0; s < P; ++s) fb[s] = right(s);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int t = s / PER, j = s % PER, k = j % 5;
+    float rx[5];
+    __builtin_amdgcn_sched_barrier(0);
+    mx_static_for(std::make_integer_sequence<int, S>{}, [&](auto s_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int t = s / PER, j = s % PER, k = j % 5;
         const mx_v8i b = mx_frag(fb[s % P]);
-        if (s + P < S) fb[s % P] = right(s + P);
+        if constexpr (s + P < S) fb[s % P] = right(s + P);
         acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(j >= 5 ? ao[k] : an[k], b, acc[t], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        asm volatile("" : "+v"(acc[t]));      // keeps the instruction at this place among the ordered statements around it
+
+        // staging of the next row: unit v after matrix instruction v * S / UNITS
+        mx_static_for(std::make_integer_sequence<int, UNITS>{}, [&](auto v_c) __attribute__((always_inline)) {
+            constexpr int v = decltype(v_c)::value;
+            if constexpr (v * S / UNITS == s && !(MX_X & 1)) {
+                constexpr int g = STEADY ? v / 2 : v;                 // round: entering row first, then the leaving row
+                constexpr bool old = g >= G::ROUNDS;
+                constexpr int i = old ? g - G::ROUNDS : g;
+                uint32_t w = old ? st.wo[i] : st.wn[i];
+                if constexpr (old && i >= RR) w ^= st.flip[i - RR];   // the leaving row's left words are complemented
+                if constexpr (!STEADY || (v & 1) == 0) {
+                    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(st.hx) : "v"(w << 3), "s"(m88), "v"(c22));
+                    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(st.hy) : "v"(w << 2), "s"(m88), "v"(c22));
+                }
+                if constexpr (!STEADY || (v & 1) == 1) {
+                    uint4 e;
+                    e.x = st.hx; e.y = st.hy;
+                    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.z) : "v"(w << 1), "s"(m88), "v"(c22));
+                    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.w) : "v"(w), "s"(m88), "v"(c22));
+                    (old ? nxt_o : nxt_n)[i * 64 + lane] = e;
+                    if constexpr (i < RR) {
+                        if constexpr (old) st.wo[i] = right_old[st.roff[i]]; else st.wn[i] = right_new[st.roff[i]];
+                    } else {
+                        if constexpr (old) st.wo[i] = st.src[i - RR][off_old]; else st.wn[i] = st.src[i - RR][off_new];
+                    }
+                }
+            }
+        });
+
+        if constexpr (STEADY && !(MX_X & 2)) {
+            // left view
+            if constexpr (t == 0 && j < 8) {                           // last tile of the previous row
+                st.best[2 * j] = mx_max(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, T - 1, 2 * j));
+                st.best[2 * j + 1] = mx_max(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, T - 1, 2 * j + 1));
+            }
+            if constexpr (t == 1 && j < 8) { MX_RED_A(j); }
+            if constexpr (t == 2 && j == 0) { MX_RED_B(0); MX_RED_B(1); }
+            if constexpr (t == 2 && j == 1) { MX_RED_B(2); MX_RED_B(3); }
+            if constexpr (t == 2 && j == 2) { MX_RED_C(); }
+            if constexpr (t == 2 && j == 3) { mx_reduce_tail<T>(st, lane); st.out += st.out_stride; }
+            if constexpr (t == 2 && j >= 5 && j < 9) {                 // tiles 0 and 1 of this row
+#pragma unroll
+                for (int i = 4 * (j - 5); i < 4 * (j - 5) + 4; ++i)
+                    st.best[i] = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
+            }
+            if constexpr (t >= 3 && j < 8) {                           // tile t - 1 of this row
+                st.best[2 * j] = mx_max(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, t - 1, 2 * j));
+                st.best[2 * j + 1] = mx_max(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, t - 1, 2 * j + 1));
+            }
+            // right view: tile t - 1 of this row, or the last tile of the previous row
+            if constexpr (BOTH) {
+                constexpr int u = t == 0 ? T - 1 : t - 1;
+                if constexpr (j == 4) mx_right_a<T, EDGE, u>(acc, st, rx);
+                if constexpr (j == 8) mx_right_b<T, EDGE, u>(acc, st, rx);
+                if constexpr (j == 9) {
+                    mx_right_c<u>(st.part, rx, swap32);
+                    if constexpr (t == 0) st.part += st.part_stride;  // the following tiles belong to this row
+                }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// Between the first five rows and the steady state: the first output row's tiles 0 .. T-2.
+template <int T, bool BOTH, bool EDGE>
+__device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState<T> &st, int swap32) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float b = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
+#pragma unroll
+        for (int u = 2; u < T - 1; ++u) b = mx_max(b, mx_elem_l<T, EDGE>(acc, st, u, i));
+        st.best[i] = b;
     }
-    __builtin_amdgcn_wave_barrier();
-    if (OUTPUT) {
-        float best[16];
+    if (BOTH) {
+        mx_static_for(std::make_integer_sequence<int, T - 1>{}, [&](auto u_c) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_c)::value;
+            float rx[5];
+            mx_right_a<T, EDGE, u>(acc, st, rx);
+            mx_right_b<T, EDGE, u>(acc, st, rx);
+            mx_right_c<u>(st.part, rx, swap32);
+        });
+    }
+}
+
+// After the last row of a strip: its last tile, the lane reduction and the stores (nothing follows to hide them behind).
+template <int T, bool BOTH, bool EDGE>
+__device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<T> &st, int lane, int swap32) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, T - 1, i));
+    MX_RED_A(0); MX_RED_A(1); MX_RED_A(2); MX_RED_A(3); MX_RED_A(4); MX_RED_A(5); MX_RED_A(6); MX_RED_A(7);
+    MX_RED_B(0); MX_RED_B(1); MX_RED_B(2); MX_RED_B(3);
+    MX_RED_C();
+    mx_reduce_tail<T>(st, lane);
+    if (BOTH) {
+        float rx[5];
+        mx_right_a<T, EDGE, T - 1>(acc, st, rx);
+        mx_right_b<T, EDGE, T - 1>(acc, st, rx);
+        mx_right_c<T - 1>(st.part, rx, swap32);
+    }
+}
+
+// Strip of one x-block: census rows y_lo-2 .. y_hi+1, output rows y_lo .. y_hi-1.
+template <int T, bool BOTH, bool EDGE>
+__device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::ROUNDS * 64], const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
+                                         int cols, int max_disp, int xl0, int y_lo, int n_rows, int lane, float *__restrict__ disp,
+                                         float *__restrict__ part_row0, long part_stride) {
+    using G = MxGeom<T>;
+    constexpr int RR = MxState<T>::RR;
+    const int n = lane & 31, h = lane >> 5;
+    const int r0 = xl0 - 32 * (T - 1);               // right column of tile 0, lane 0
+    const int swap32 = (lane ^ 32) * 4;
+
+    // Accumulator element i of tile t is (left column xl0 + m, right column r0 + 32 t + n).  It starts at
+    // (1023 - d) / 1024, so that the running window score carries its disparity tag below the integer part
+    // (21 significant bits: exact), or near -2^20 when the pair is inadmissible.  Left view: right column >= 5;
+    // right view: right column >= 2 and left column <= cols-6 (the mirror image of the left view's rule); where the
+    // two differ (EDGE blocks) the accumulators admit both and each view adds its own penalty when it reads them.
+    mx_v16f acc[T];
+    MxState<T> st;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int xr = r0 + 32 * t + n;
+        st.pen_l[t] = xr >= 5 ? 0.0f : -2097152.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            float b = acc[0][i];
-#pragma unroll
-            for (int t = 1; t + 1 < T; t += 2) b = __builtin_fmaxf(__builtin_fmaxf(b, acc[t][i]), acc[t + 1][i]);
-            if ((T & 1) == 0) b = __builtin_fmaxf(b, acc[T - 1][i]);
-            best[i] = b;
+            const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int d = xl0 + m - xr;
+            const bool ok = d >= 0 && d < max_disp && xr >= (BOTH ? 2 : 5);
+            acc[t][i] = ok ? (float)(1023 - d) * (1.0f / 1024.0f) : -1048576.0f;
         }
-        float z = mx_reduce16(best, lane);                       // lane l: register (l & 15) over its 16-lane row
-        const float zo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, z), 0x401f));   // lane ^ 16
-        z = __builtin_fmaxf(z, zo);
-        // key = window score + (1023 - d) / 1024; an inadmissible pair sits near -2^20
-        const float frac = z - __builtin_floorf(z);
-        const float d = z < -524288.0f ? 0.0f : 1023.0f - frac * 1024.0f;
-        if ((lane & 16) == 0) *out = d;
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.pen_r[i] = xl0 + (i & 3) + 8 * (i >> 2) + 4 * h <= cols - 6 ? 0.0f : -2097152.0f;
+
+    // staging: word q of a row is right word (r0 - 2) * 2 + q for q < RW, left word (xl0 - 2) * 2 + q - RW after it;
+    // words left of the frame and the padding of the last round are clamped: they only feed inadmissible pairs
+    const long row_words = (long)cols * 2;
+    const uint32_t *const cl0 = cl + (long)(y_lo - 2) * row_words, *const cr0 = cr + (long)(y_lo - 2) * row_words;
+#pragma unroll
+    for (int i = 0; i < G::ROUNDS; ++i) {
+        const int q = min(i * 64 + lane, G::WORDS - 1);
+        const bool is_left = q >= G::RW;
+        if (i < RR) {
+            st.roff[i < RR ? i : 0] = (uint32_t)max((r0 - 2) * 2 + q, 0);
+        } else {
+            st.src[i >= RR ? i - RR : 0] = is_left ? cl0 + (xl0 - 2) * 2 + (q - G::RW) : cr0 + max((r0 - 2) * 2 + q, 0);
+            st.flip[i >= RR ? i - RR : 0] = is_left ? 0xffffffffu : 0u;
+        }
+    }
+    auto word = [&](int i, int r) -> uint32_t {       // word of staging round i in census row r of the strip
+        return i < RR ? cr0[r * row_words + st.roff[i < RR ? i : 0]] : st.src[i >= RR ? i - RR : 0][r * row_words];
+    };
+    const int last = n_rows - 1;
+    const int i_out = lane & 15;
+    st.out = disp + (long)y_lo * cols + xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h;
+    st.out_stride = cols;
+    st.part = part_row0 + n;
+    st.part_stride = part_stride;
+
+    // row 0 is staged here, every other row while its predecessor runs
+    {
+        uint32_t c22;
+        asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
+#pragma unroll
+        for (int i = 0; i < G::ROUNDS; ++i) lds[0][0][i * 64 + lane] = mx_expand(word(i, 0), c22);
+#pragma unroll
+        for (int i = 0; i < G::ROUNDS; ++i) { st.wn[i] = word(i, 1); st.wo[i] = 0u; }
+    }
+    // row r stages row r+1 (entering) with row r-4 (leaving) and fetches the words of rows r+2 and r-3
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) {
+        const long on = (long)min(r + 2, last) * row_words, oo = (long)max(r - 3, 0) * row_words;
+        mx_row<T, false, BOTH, EDGE>(acc, lds[r & 1][0], lds[r & 1][1], lds[(r + 1) & 1][0], lds[(r + 1) & 1][1], st,
+                                     cr0 + on, cr0 + oo, on, oo, lane, swap32);
+    }
+    mx_first_output<T, BOTH, EDGE>(acc, st, swap32);
+#pragma unroll 1
+    for (int r = 5; r < n_rows; ++r) {
+        const long on = (long)min(r + 2, last) * row_words, oo = (long)(r - 3) * row_words;
+        mx_row<T, true, BOTH, EDGE>(acc, lds[r & 1][0], lds[r & 1][1], lds[(r + 1) & 1][0], lds[(r + 1) & 1][1], st,
+                                    cr0 + on, cr0 + oo, on, oo, lane, swap32);
+    }
+    mx_last_output<T, BOTH, EDGE>(acc, st, lane, swap32);
 }
 
 // grid: (x-blocks, strips, frames), one wavefront per block.  x-block b owns output columns [xl0, xl0 + 32),
 // xl0 = min(2 + 32 b, cols - 34) (the last block is shifted left to end at column cols-3).
 // Requires cols >= 36, rows >= 5, max_disp <= 32 * (T - 1).
-template <int T>
+// BOTH: also stores, for every output row and x-block, the right view's best key of each of the block's 32 T right
+// columns over the block's left columns: partial[frame][row][x-block][32 T] (svx_mx_right_disparity merges them).
+template <int T, bool BOTH>
 __global__ __launch_bounds__(64) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                           int rows, int cols, int max_disp, int strip_rows,
-                                                          float *__restrict__ disp_all, int write_border) {
+                                                          float *__restrict__ disp_all, int write_border, float *__restrict__ partial) {
     using G = MxGeom<T>;
-    __shared__ uint4 lds[2][G::ROUNDS * 64];            // [entering row, leaving row][census word, padded to whole rounds]
+    __shared__ uint4 lds[2][2][G::ROUNDS * 64];      // [row parity][entering row, leaving row][census word, padded to whole rounds]
     const int lane = threadIdx.x;
     const int n = lane & 31, h = lane >> 5;
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
@@ -167,74 +391,14 @@ __global__ __launch_bounds__(64) void dense_wta_mx_kernel(const uint32_t *__rest
     float *disp = disp_all + bz * npx;
     const int n_xblocks = gridDim.x;
     const int xl0 = min(2 + (int)bx * MX_M, cols - 2 - MX_M);
-    const int r0 = xl0 - 32 * (T - 1);               // right column of tile 0, lane 0
     const int y_lo = 2 + (int)by * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
     const int n_rows = y_hi - y_lo + 4;              // census rows y_lo-2 .. y_hi+1
-
-    // Accumulator element i of tile t is (left column xl0 + m, right column r0 + 32 t + n).  It starts at
-    // (1023 - d) / 1024, so that the running window score carries its disparity tag below the integer part
-    // (21 significant bits: exact), or near -2^20 when the pair is inadmissible.
-    mx_v16f acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int xr = r0 + 32 * t + n, d = xl0 + m - xr;
-            const bool ok = d >= 0 && d < max_disp && xr >= 5;
-            acc[t][i] = ok ? (float)(1023 - d) * (1.0f / 1024.0f) : -1048576.0f;
-        }
-
-    // staging: word q of a row is right word (r0 - 2) * 2 + q for q < RW, left word (xl0 - 2) * 2 + q - RW after it;
-    // words left of the frame and the padding of the last round are clamped: they only feed inadmissible pairs
-    const uint32_t *src[G::ROUNDS];
-    uint32_t left_mask[G::ROUNDS];
-#pragma unroll
-    for (int i = 0; i < G::ROUNDS; ++i) {
-        const int q = min(i * 64 + lane, G::WORDS - 1);
-        const bool is_left = q >= G::RW;
-        src[i] = is_left ? cl + (xl0 - 2) * 2 + (q - G::RW) : cr + max((r0 - 2) * 2 + q, 0);
-        left_mask[i] = is_left ? 0xffffffffu : 0u;
-    }
-    static_assert(G::RW >= (G::ROUNDS - 2) * 64, "left words must lie in the last two rounds");
-    auto fetch = [&](int r, uint32_t (&w)[G::ROUNDS]) {
-        const long rowoff = (long)(y_lo - 2 + r) * cols * 2;
-#pragma unroll
-        for (int i = 0; i < G::ROUNDS; ++i) w[i] = src[i][rowoff];
-    };
-    uint32_t wn[G::ROUNDS], wo[G::ROUNDS];
-    const int i_out = lane & 15;
-    float *out = disp + (long)y_lo * cols + xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h;
-    const int last = n_rows - 1;
-
-    fetch(0, wn);
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        uint32_t wc[G::ROUNDS];
-#pragma unroll
-        for (int i = 0; i < G::ROUNDS; ++i) wc[i] = wn[i];
-        fetch(r + 1, wn);
-        mx_row<T, false, false>(acc, lds[0], lds[1], wc, wc, 0u, 0u, lane, out);
-    }
-    {
-        uint32_t wc[G::ROUNDS];
-#pragma unroll
-        for (int i = 0; i < G::ROUNDS; ++i) wc[i] = wn[i];
-        fetch(min(5, last), wn);
-        fetch(0, wo);
-        mx_row<T, false, true>(acc, lds[0], lds[1], wc, wc, 0u, 0u, lane, out);
-        out += cols;
-    }
-#pragma unroll 1
-    for (int r = 5; r < n_rows; ++r) {
-        uint32_t wc[G::ROUNDS], wd[G::ROUNDS];
-#pragma unroll
-        for (int i = 0; i < G::ROUNDS; ++i) { wc[i] = wn[i]; wd[i] = wo[i]; }
-        fetch(min(r + 1, last), wn);
-        fetch(r - 4, wo);
-        mx_row<T, true, true>(acc, lds[0], lds[1], wc, wd, left_mask[G::ROUNDS - 1], left_mask[G::ROUNDS - 2], lane, out);
-        out += cols;
-    }
+    const long part_stride = (long)n_xblocks * (32 * T);
+    float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)bx * (32 * T) : nullptr;
+    // blocks in which the two views admit different pairs
+    const bool edge = BOTH && (xl0 - 32 * (T - 1) < 5 || xl0 + MX_M - 1 > cols - 6);
+    if (edge) mx_strip<T, BOTH, BOTH>(lds, cl, cr, cols, max_disp, xl0, y_lo, n_rows, lane, disp, part_row0, part_stride);
+    else mx_strip<T, BOTH, false>(lds, cl, cr, cols, max_disp, xl0, y_lo, n_rows, lane, disp, part_row0, part_stride);
 
     if (write_border) {
         // rows outside [2, rows-2) over this block's columns, and the two border columns on either side
@@ -248,19 +412,110 @@ __global__ __launch_bounds__(64) void dense_wta_mx_kernel(const uint32_t *__rest
     }
 }
 
+// Right view from the partial keys: right pixel xr can match left columns xr .. xr + max_disp - 1, which lie in the
+// x-blocks whose first left column xl0 satisfies xr - 31 <= xl0 <= xr + 32 (T - 1); block b keeps xr in slot
+// xr - (xl0 - 32 (T - 1)).
+template <int T>
+__device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, int xr, int cols, int n_xblocks) {
+    float best = -1048576.0f;
+    const int b_first = max((xr - 31 - 2 + MX_M - 1) / MX_M, 0);       // smallest b with 2 + 32 b >= xr - 31
+#pragma unroll
+    for (int k = 0; k < T + 1; ++k) {
+        const int b = min(b_first + k, n_xblocks - 1);
+        const int xl0 = min(2 + b * MX_M, cols - 2 - MX_M);
+        const int slot = xr - (xl0 - 32 * (T - 1));
+        const bool ok = slot >= 0 && slot < 32 * T;
+        const float v = prow[(long)b * (32 * T) + min(max(slot, 0), 32 * T - 1)];
+        best = fmaxf(best, ok ? v : -1048576.0f);
+    }
+    return mx_decode(best);
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void mx_right_view_merge_kernel(const float *__restrict__ partial, int rows, int cols, int n_xblocks,
+                                                                  float *__restrict__ disp_right_all) {
+    const int xr = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (xr >= cols) return;
+    float *out = disp_right_all + ((long)blockIdx.z * rows + y) * cols;
+    if (xr < 2 || xr >= cols - 2 || y < 2 || y >= rows - 2) { out[xr] = 0.0f; return; }
+    const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * 32 * T);
+    out[xr] = svx_mx_right_disparity<T>(prow, xr, cols, n_xblocks);
+}
+
+// Left-right check straight from the partial keys (the rule of svx_lr_check with the right disparity merged on demand).
+template <int T>
+__global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl_all, const float *__restrict__ partial, int rows, int cols,
+                                                          int n_xblocks, float threshold, float invalid) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
+    float *dl = dl_all + ((long)blockIdx.z * rows + y) * cols;
+    const float d1 = dl[x];
+    const int xr = x - (int)d1;
+    if (xr < 2) { dl[x] = invalid; return; }
+    const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * 32 * T);
+    if (fabsf(svx_mx_right_disparity<T>(prow, xr, cols, n_xblocks) - d1) > threshold) dl[x] = invalid;
+}
+
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX_M + 4 && rows >= 5 && max_disp >= 1 && max_disp <= 128; }
 
+static int mx_tiles(int max_disp) { return max_disp <= 64 ? 3 : 5; }
+static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }
+
+size_t svx_mx_partial_words(int rows, int cols, int n_frames, int max_disp) {
+    return (size_t)n_frames * rows * mx_xblocks(cols) * 32 * mx_tiles(max_disp);
+}
+
 // Left-view search on two-word descriptors; see svx_dense.hip for the meaning of the arguments.
+// partial != nullptr: also the right view's partial keys (svx_mx_partial_words floats).
 int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
-                        float *disparity, int write_border) {
+                        float *disparity, int write_border, float *partial) {
     const int strip_rows = MX_MAX_STRIP;
     const int n_strips = (rows - 4 + strip_rows - 1) / strip_rows;
-    const int n_xblocks = (cols - 4 + MX_M - 1) / MX_M;
-    dim3 grid(n_xblocks, n_strips, n_frames);
-    if (max_disp <= 64)
-        dense_wta_mx_kernel<3><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border);
-    else
-        dense_wta_mx_kernel<5><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border);
+    dim3 grid(mx_xblocks(cols), n_strips, n_frames);
+    const int T = mx_tiles(max_disp);
+    if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
+    else if (T == 3) dense_wta_mx_kernel<3, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
+    else if (!partial) dense_wta_mx_kernel<5, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
+    else dense_wta_mx_kernel<5, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
     SVX_LAUNCH_CHECK(ctx, "dense_wta_mx_kernel");
     return SVX_OK;
+}
+
+// After svx_launch_mx_sweep with partial keys: the right disparity map (disp_right != nullptr) or the left-right
+// check of disp_left in place.
+int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int max_disp,
+                        float *disp_left, float *disp_right, float lr_threshold) {
+    const dim3 grid(svx_cdiv(cols, 256), rows, n_frames);
+    const int nb = mx_xblocks(cols);
+    if (mx_tiles(max_disp) == 3) {
+        if (disp_right) mx_right_view_merge_kernel<3><<<grid, 256, 0, ctx->stream>>>(partial, rows, cols, nb, disp_right);
+        else mx_lr_check_kernel<3><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, rows, cols, nb, lr_threshold, -1.0f);
+    } else {
+        if (disp_right) mx_right_view_merge_kernel<5><<<grid, 256, 0, ctx->stream>>>(partial, rows, cols, nb, disp_right);
+        else mx_lr_check_kernel<5><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, rows, cols, nb, lr_threshold, -1.0f);
+    }
+    SVX_LAUNCH_CHECK(ctx, "mx right view kernel");
+    return SVX_OK;
+}
+
+// The matrix-core form of svx_dense_wta_both on two-word descriptors (max_disp <= 128, cols >= 36, rows >= 5), run
+// whatever the library's default choice of kernel is: left map, and with disp_right != NULL the right map from the
+// same accumulators.  Same results as svx_dense_wta / svx_dense_wta_both.
+SVX_API int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
+                                 int max_disp, float *disp_left, float *disp_right) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, census_left && census_right && disp_left, SVX_ERR_INVALID_ARG, "svx_dense_wta_matrix: null pointer");
+    SVX_REQUIRE(ctx, n_frames >= 1 && n_frames <= 65535 && rows <= 65535, SVX_ERR_INVALID_ARG, "svx_dense_wta_matrix: bad frame count or size");
+    SVX_REQUIRE(ctx, svx_mx_sweep_eligible(rows, cols, max_disp), SVX_ERR_UNSUPPORTED,
+                "svx_dense_wta_matrix: needs cols >= 36, rows >= 5, 1 <= max_disp <= 128");
+    if (!disp_right) return svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, nullptr);
+    const size_t per_frame = svx_mx_partial_words(rows, cols, 1, max_disp);
+    SVX_REQUIRE(ctx, per_frame * n_frames * sizeof(float) <= ((size_t)4 << 30), SVX_ERR_UNSUPPORTED, "svx_dense_wta_matrix: batch too large for one call");
+    void *ws;
+    rc = svx_ws_reserve(ctx, per_frame * n_frames * sizeof(float), &ws);
+    if (rc) return rc;
+    rc = svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, (float *)ws);
+    if (rc) return rc;
+    return svx_launch_mx_right(ctx, (const float *)ws, rows, cols, n_frames, max_disp, disp_left, disp_right, 0.0f);
 }

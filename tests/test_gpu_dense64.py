@@ -73,6 +73,34 @@ def test_dense_wta_both_views_from_one_sweep(ctx, rows, cols, max_disp, words):
         assert np.array_equal(dr[f], wr), (f, np.argwhere(dr[f] != wr)[:5], dr[f][dr[f] != wr][:5], wr[dr[f] != wr][:5])
 
 
+@pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (12, 40, 64), (30, 150, 128), (5, 36, 1), (110, 90, 70), (9, 300, 100),
+                                                 (101, 37, 33), (7, 200, 128), (40, 133, 65)])
+def test_dense_wta_matrix_matches_oracle(ctx, rows, cols, max_disp):
+    """The matrix-core form: both views bit for bit, on descriptors with few distinct values (many cost ties)."""
+    rng = np.random.default_rng(rows * 1000 + cols + max_disp)
+    shape = (2, rows, cols, 2)
+    cl = rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x01010101 if cols % 2 else 0xffffffff)
+    cr = np.roll(cl, -3, axis=2) ^ (rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x00010000))
+    dl, dr = ctx.dense_wta_matrix(dev_u32(cl), dev_u32(cr), max_disp)
+    dl0, _ = ctx.dense_wta_matrix(dev_u32(cl), dev_u32(cr), max_disp, both=False)
+    dl, dr, dl0 = dl.cpu().numpy(), dr.cpu().numpy(), dl0.cpu().numpy()
+    for f in range(2):
+        want_l, want_r = O.dense_wta_words(cl[f], cr[f], max_disp, 0), O.dense_wta_words(cl[f], cr[f], max_disp, 1)
+        assert np.array_equal(dl[f], want_l), (f, np.argwhere(dl[f] != want_l)[:5])
+        assert np.array_equal(dl0[f], want_l), (f, np.argwhere(dl0[f] != want_l)[:5])
+        assert np.array_equal(dr[f], want_r), (f, np.argwhere(dr[f] != want_r)[:5])
+
+
+def test_dense_wta_matrix_refuses_what_it_does_not_cover(ctx):
+    import stereovision_amd as S
+    cl = dev_u32(np.zeros((1, 8, 30, 2), np.uint32))
+    with pytest.raises(S.SvxError):
+        ctx.dense_wta_matrix(cl, cl, 16)
+    cl = dev_u32(np.zeros((1, 8, 64, 2), np.uint32))
+    with pytest.raises(S.SvxError):
+        ctx.dense_wta_matrix(cl, cl, 129)
+
+
 def test_left_view_one_word_is_the_reference_search(ctx):
     """svx_dense_wta(words=1, left view) == the reference-pinned a8 restatement on its interior."""
     rng = np.random.default_rng(3)
