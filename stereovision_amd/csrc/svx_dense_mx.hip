@@ -1,17 +1,21 @@
-// Dense 5x5-aggregated Hamming winner-takes-all on the matrix cores (two-word descriptors, left view).
+// Dense 5x5-aggregated Hamming winner-takes-all on the matrix cores (two-word descriptors, left view and, from the same
+// accumulators, the right view).
 //
-// Same result as the vector sweep of svx_dense.hip (search rule of denseCensusStereo/denseCensusStereo.cpp:87-131
+// Same results as the vector sweep of svx_dense.hip (search rule of denseCensusStereo/denseCensusStereo.cpp:87-131
 // on 64-bit descriptors); the cost values are formed as dot products.  With every descriptor bit b written as the
 // number 1 - 2b, the dot product of two 64-element descriptors is 64 - 2 * Hamming distance, and the cost of a
 // 5-column window is the dot product of the two windows' concatenated descriptors (K = 5 x 64).  One wavefront
 // owns 32 left columns and the 32*T right columns they can match (T tiles of 32 x 32 left/right pairs): per census
 // row it adds the row that enters the 5-row window (5 k-steps per tile) and subtracts the row that leaves it (the
 // same products with the left operand negated), so the accumulators always hold
-//     acc[tile][left column m][right column n] = 1600 - 2 * window cost.
+//     acc[tile][left column m][right column n] = 1600 - 2 * window cost  (+ a tag, below).
 // Operands are fp4 (E2M1: +1.0 = 0x2, -1.0 = 0xA) with unit block scales: every product and sum is an exact small
-// integer in the f32 accumulators.  The disparity tag and the admissibility mask are one fused multiply-add per
-// accumulator element (key = acc * 1024 + bias, bias = 1023 - d or a large negative number), the winner of a left
-// column is the maximum key over the tiles and over the 32 lanes that hold its right columns.
+// integer in the f32 accumulators.  The disparity tag and the admissibility mask live in the accumulators too: an
+// element starts at (1023 - d) / 1024, or near -2^20 when the pair is inadmissible, so the running sum is its own
+// sort key (21 significant bits, exact) and no instruction is spent on forming keys.  The winner of a left column is
+// the maximum over the tiles and over the 32 lanes that hold its right columns; the winner of a right column is the
+// maximum over the 16 registers and the two lane halves that hold its left columns, merged over the x-blocks that
+// reach it by a second kernel.
 #include "svx_common.hpp"
 #include <utility>
 
@@ -20,6 +24,9 @@ typedef float mx_v16f __attribute__((ext_vector_type(16)));
 
 #ifndef MX_X
 #define MX_X 0      // measurement aid: bit 0 drops the staging work, bit 1 the winner selection (results are wrong then)
+#endif
+#ifndef MX_P
+#define MX_P 4      // right operands fetched this many matrix instructions ahead
 #endif
 constexpr int MX_M = 32;                 // left columns per wavefront
 constexpr int MX_MAX_STRIP = 96;
@@ -30,6 +37,14 @@ struct MxGeom {
     static constexpr int LPX = MX_M + 4;
     static constexpr int RW = 2 * RPX, LW = 2 * LPX, WORDS = RW + LW;   // census words per staged row
     static constexpr int ROUNDS = (WORDS + 63) / 64;
+    // LDS image of a staged row: one plane per descriptor word (= per k-half of the matrix instruction), a pixel's
+    // 32 fp4 values (16 bytes) at [word][pixel], right pixels first.  A 16-lane group of a 16-byte read then covers
+    // 256 consecutive bytes (with the two words of a pixel side by side it would hit every bank twice).  The planes
+    // are PLANE pixels apart, PLANE = 8 mod 16, so that the 8 + 8 lanes of a write group land in different banks; the
+    // lanes of the last staging round that hold no word write behind the planes.
+    static constexpr int PLANE = RPX + LPX;
+    static constexpr int SLOTS = 2 * PLANE + (ROUNDS * 64 - WORDS);
+    static_assert(PLANE % 16 == 8, "plane offset must alternate the bank halves");
 };
 
 // 32 descriptor bits -> 32 fp4 values: dword j holds bits j, j+4, .. j+28 (the same permutation on both operands).
@@ -84,6 +99,7 @@ struct MxState {
     uint32_t roff[RR];                                       // rounds < RR: this lane's word offset in a right row
     const uint32_t *src[G::ROUNDS - RR];                     // the other rounds: this lane's word in row 0 of the strip
     uint32_t flip[G::ROUNDS - RR];                           // all ones where that word is a left word
+    int slot0, slot_last;                                    // where this lane's word of round 0 / of the last round goes in a staged row
     uint32_t hx, hy;                                         // first half of the expansion under way
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
     float pen_l[T], pen_r[16];                               // border blocks: what each view must not use (0 or -2^21)
@@ -152,7 +168,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *__restric
                                        const uint32_t *__restrict__ right_new, const uint32_t *__restrict__ right_old,
                                        long off_new, long off_old, int lane, int swap32) {
     using G = MxGeom<T>;
-    constexpr int PER = STEADY ? 10 : 5, S = T * PER, P = 4, RR = MxState<T>::RR;
+    constexpr int PER = STEADY ? 10 : 5, S = T * PER, P = MX_P, RR = MxState<T>::RR;
     constexpr int UNITS = STEADY ? 4 * G::ROUNDS : 2 * G::ROUNDS;     // staging work in halves of a round, or whole rounds
     static_assert(S >= UNITS, "one unit of staging work per matrix instruction at most");
     static_assert(T >= 3, "the fold schedule needs three tiles");
@@ -163,12 +179,12 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *__restric
     mx_v8i an[5], ao[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        an[k] = mx_frag(cur_n[G::RW + (n + k) * 2 + h]);
-        if (STEADY) ao[k] = mx_frag(cur_o[G::RW + (n + k) * 2 + h]);
+        an[k] = mx_frag(cur_n[h * G::PLANE + G::RPX + n + k]);
+        if (STEADY) ao[k] = mx_frag(cur_o[h * G::PLANE + G::RPX + n + k]);
     }
     auto right = [&](int s) -> uint4 {
         const int t = s / PER, j = s % PER, k = j % 5;
-        return (j >= 5 ? cur_o : cur_n)[(32 * t + n + k) * 2 + h];
+        return (j >= 5 ? cur_o : cur_n)[h * G::PLANE + 32 * t + n + k];
     };
     uint4 fb[P];
 #pragma unroll
@@ -201,7 +217,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *__restric
                     e.x = st.hx; e.y = st.hy;
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.z) : "v"(w << 1), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.w) : "v"(w), "s"(m88), "v"(c22));
-                    (old ? nxt_o : nxt_n)[i * 64 + lane] = e;
+                    (old ? nxt_o : nxt_n)[i == G::ROUNDS - 1 ? st.slot_last : st.slot0 + i * 32] = e;
                     if constexpr (i < RR) {
                         if constexpr (old) st.wo[i] = right_old[st.roff[i]]; else st.wn[i] = right_new[st.roff[i]];
                     } else {
@@ -286,7 +302,7 @@ __device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<
 
 // Strip of one x-block: census rows y_lo-2 .. y_hi+1, output rows y_lo .. y_hi-1.
 template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::ROUNDS * 64], const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
+__device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::SLOTS], const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
                                          int cols, int max_disp, int xl0, int y_lo, int n_rows, int lane, float *__restrict__ disp,
                                          float *__restrict__ part_row0, long part_stride) {
     using G = MxGeom<T>;
@@ -335,6 +351,11 @@ __device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::ROUNDS * 
     auto word = [&](int i, int r) -> uint32_t {       // word of staging round i in census row r of the strip
         return i < RR ? cr0[r * row_words + st.roff[i < RR ? i : 0]] : st.src[i >= RR ? i - RR : 0][r * row_words];
     };
+    st.slot0 = (lane & 1) * G::PLANE + (lane >> 1);
+    {
+        const int q = (G::ROUNDS - 1) * 64 + lane;
+        st.slot_last = q < G::WORDS ? (q & 1) * G::PLANE + (q >> 1) : 2 * G::PLANE + (q - G::WORDS);
+    }
     const int last = n_rows - 1;
     const int i_out = lane & 15;
     st.out = disp + (long)y_lo * cols + xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h;
@@ -347,7 +368,7 @@ __device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::ROUNDS * 
         uint32_t c22;
         asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
 #pragma unroll
-        for (int i = 0; i < G::ROUNDS; ++i) lds[0][0][i * 64 + lane] = mx_expand(word(i, 0), c22);
+        for (int i = 0; i < G::ROUNDS; ++i) lds[0][0][i == G::ROUNDS - 1 ? st.slot_last : st.slot0 + i * 32] = mx_expand(word(i, 0), c22);
 #pragma unroll
         for (int i = 0; i < G::ROUNDS; ++i) { st.wn[i] = word(i, 1); st.wo[i] = 0u; }
     }
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(64) void dense_wta_mx_kernel(const uint32_t *__rest
                                                           int rows, int cols, int max_disp, int strip_rows,
                                                           float *__restrict__ disp_all, int write_border, float *__restrict__ partial) {
     using G = MxGeom<T>;
-    __shared__ uint4 lds[2][2][G::ROUNDS * 64];      // [row parity][entering row, leaving row][census word, padded to whole rounds]
+    __shared__ uint4 lds[2][2][G::SLOTS];            // [row parity][entering row, leaving row][see MxGeom]
     const int lane = threadIdx.x;
     const int n = lane & 31, h = lane >> 5;
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
