@@ -623,9 +623,126 @@ __global__ __launch_bounds__(256) void census9x7_pixel_kernel(const uint8_t *__r
 #include "svx_census97_px.inc"
 constexpr int C97T_W = 256, C97T_H = 16, C97T_LROW = C97T_W / 4 + 2 + 1;   // dwords per staged row (+1 pad)
 
+// Bytes b and b+1 of the 12 bytes held in three dwords, each widened to a 16-bit field.
+template <int B>
+__device__ __forceinline__ uint32_t c97_pair(const uint32_t (&r)[3]) {
+    constexpr int k = B / 4, k1 = (B + 1) / 4;
+    constexpr uint32_t sel = (uint32_t)(B % 4) | (0x0cu << 8) | ((uint32_t)(k1 == k ? (B + 1) % 4 : 4 + (B + 1) % 4) << 16) | (0x0cu << 24);
+    return __builtin_amdgcn_perm(r[k1 == k ? (k < 2 ? k + 1 : k) : k1], r[k], sel);
+}
+
+// The tile kernel's arithmetic on pixel pairs: two pixels sit in the 16-bit fields of a dword, `centre + 0x7fff - neighbour`
+// has bit 15 of a field set exactly when the centre is greater, and the bit goes to its place in one of four
+// 16-bit-per-pixel accumulators by a shift and a masked or: three instructions per two comparisons.
 template <bool ALIGNED>
+__device__ __forceinline__ void census9x7_tile_packed(const uint8_t *__restrict__ img_all, int rows, int cols, long total_bytes,
+                                                      uint32_t *__restrict__ out_all) {
+    __shared__ uint32_t tile[(C97T_H + 6) * C97T_LROW];
+    const long n = (long)rows * cols;
+    const uint8_t *img = img_all + (long)blockIdx.z * n;
+    uint32_t *out = out_all + (long)blockIdx.z * n * 2;
+    const int x0 = blockIdx.x * C97T_W, y0 = blockIdx.y * C97T_H;
+    for (int i = threadIdx.x; i < (C97T_H + 6) * C97T_LROW; i += 256) {
+        const int r = i / C97T_LROW, k = i - r * C97T_LROW;
+        const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * k;
+        uint32_t v = 0u;
+        if (ALIGNED) {
+            if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = *reinterpret_cast<const uint32_t *>(img + (long)gy * cols + gx);
+        } else if (gy >= 0 && gy < rows && gx > -4 && gx < cols) {
+            const long a = (long)blockIdx.z * n + (long)gy * cols + gx;         // byte offset in the batch, may be negative by < 4
+            const long a0 = a & ~3L;
+            if (a0 >= 0 && a0 + 8 <= total_bytes) {
+                const uint32_t d0 = *reinterpret_cast<const uint32_t *>(img_all + a0), d1 = *reinterpret_cast<const uint32_t *>(img_all + a0 + 4);
+                v = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)(a & 3));
+            } else {                                                            // the first and last bytes of the batch
+                for (int b = 0; b < 4; ++b)
+                    if (a + b >= 0 && a + b < total_bytes) v |= (uint32_t)img_all[a + b] << (8 * b);
+            }
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = x0 + lane * 4;
+    if (x >= cols) return;
+    uint32_t R[10][3];                 // staged rows wave*4 .. wave*4+9 = image rows y-3 .. y+6 of the lane's first row y
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t *q = tile + (wave * 4 + r) * C97T_LROW + lane;
+        R[r][0] = q[0]; R[r][1] = q[1]; R[r][2] = q[2];
+    }
+    // acc[j][pair][w]: bits 16w .. 16w+15 of the descriptors of pixels 2 pair, 2 pair + 1 of output row j
+    uint32_t acc[4][2][4], cpre[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cpre[j][0] = c97_pair<4>(R[j + 3]) + 0x7fff7fffu;
+        cpre[j][1] = c97_pair<6>(R[j + 3]) + 0x7fff7fffu;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[j][0][w] = acc[j][1][w] = 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t pr[11];
+        pr[0] = c97_pair<0>(R[r]); pr[1] = c97_pair<1>(R[r]); pr[2] = c97_pair<2>(R[r]); pr[3] = c97_pair<3>(R[r]);
+        pr[4] = c97_pair<4>(R[r]); pr[5] = c97_pair<5>(R[r]); pr[6] = c97_pair<6>(R[r]); pr[7] = c97_pair<7>(R[r]);
+        pr[8] = c97_pair<8>(R[r]); pr[9] = c97_pair<9>(R[r]); pr[10] = c97_pair<10>(R[r]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dy = r - j - 3;
+            if (dy < -3 || dy > 3) continue;
+#pragma unroll
+            for (int dx = -4; dx <= 4; ++dx) {
+                const int idx = (dy + 3) * 9 + dx + 4;
+                if (idx == 31) continue;                       // the centre itself
+                const int q = 62 - idx, w = q >> 4, pos = q & 15;
+#pragma unroll
+                for (int pair = 0; pair < 2; ++pair) {
+                    const uint32_t u = cpre[j][pair] - pr[2 * pair + dx + 4];
+                    // (shifted & mask) | acc in one instruction (left to itself the compiler pairs an and with half an or3)
+                    asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc[j][pair][w]) : "v"(pos == 15 ? u : u >> (15 - pos)), "s"(0x00010001u << pos));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = y0 + wave * 4 + j;
+        if (y >= rows) break;
+        uint32_t hi[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
+        if (y >= 3 && y < rows - 3) {
+#pragma unroll
+            for (int pair = 0; pair < 2; ++pair) {
+                lo[2 * pair] = __builtin_amdgcn_perm(acc[j][pair][1], acc[j][pair][0], 0x05040100u);
+                hi[2 * pair] = __builtin_amdgcn_perm(acc[j][pair][3], acc[j][pair][2], 0x05040100u);
+                lo[2 * pair + 1] = __builtin_amdgcn_perm(acc[j][pair][1], acc[j][pair][0], 0x07060302u);
+                hi[2 * pair + 1] = __builtin_amdgcn_perm(acc[j][pair][3], acc[j][pair][2], 0x07060302u);
+            }
+            if (ALIGNED) {                                                                               // the border columns
+                if (x < 4) hi[0] = lo[0] = hi[1] = lo[1] = hi[2] = lo[2] = hi[3] = lo[3] = 0u;            // are whole lanes
+                if (x >= cols - 4) hi[0] = lo[0] = hi[1] = lo[1] = hi[2] = lo[2] = hi[3] = lo[3] = 0u;
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (x + p < 4 || x + p >= cols - 4) hi[p] = lo[p] = 0u;
+            }
+        }
+        if (ALIGNED || (((cols & 1) == 0) && x + 3 < cols)) {
+            uint4 *o = reinterpret_cast<uint4 *>(out + ((long)y * cols + x) * 2);
+            o[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+            o[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+        } else {
+            uint2 *o = reinterpret_cast<uint2 *>(out + ((long)y * cols + x) * 2);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (x + p < cols) o[p] = make_uint2(lo[p], hi[p]);
+        }
+    }
+}
+
+template <bool ALIGNED, bool PACKED>
 __global__ __launch_bounds__(256) void census9x7_tile_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, long total_bytes,
                                                              uint32_t *__restrict__ out_all) {
+    if (PACKED) { census9x7_tile_packed<ALIGNED>(img_all, rows, cols, total_bytes, out_all); return; }
     __shared__ uint32_t tile[(C97T_H + 6) * C97T_LROW];
     const long n = (long)rows * cols;
     const uint8_t *img = img_all + (long)blockIdx.z * n;
@@ -702,11 +819,15 @@ SVX_API int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census,
     const bool fast = (((uintptr_t)img & 3u) == 0) && (((uintptr_t)census & 15u) == 0);
     const long total_bytes = (long)rows * cols * n_frames;
     const dim3 tgrid(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97T_H), n_frames);
+    // Tuning knob: SVX_CENSUS97_PACKED=0 selects the one-comparison-per-instruction form of the tile kernel.
+    static const int packed = [] { const char *e = getenv("SVX_CENSUS97_PACKED"); return e ? atoi(e) : 1; }();
     if (fast && cols % 4 == 0) {
-        census9x7_tile_kernel<true><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
+        if (packed) census9x7_tile_kernel<true, true><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
+        else census9x7_tile_kernel<true, false><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
         SVX_LAUNCH_CHECK(ctx, "census9x7_tile_kernel");
     } else if (fast && cols >= 9) {
-        census9x7_tile_kernel<false><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
+        if (packed) census9x7_tile_kernel<false, true><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
+        else census9x7_tile_kernel<false, false><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
         SVX_LAUNCH_CHECK(ctx, "census9x7_tile_kernel");
     } else {
         census9x7_pixel_kernel<<<dim3(svx_cdiv(cols, C97_W), svx_cdiv(rows, C97_H), n_frames), 256, 0, ctx->stream>>>(img, rows, cols, (uint2 *)census);
