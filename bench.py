@@ -283,7 +283,12 @@ def main():
         valu_ops = 2.0 * words * pixdisp_per_frame * F              # v_xor + v_bcnt per descriptor word per pix*disp
         # the dominant kernel's own traffic: both census batches in (4 B per word), the disparity map out, and for the
         # both-views sweep the right view's partial minima (80 words per output row, 16-column block and 64-disparity chunk)
-        part_bytes = 4.0 * 80 * F * (rows - 4) * ((cols - 4 + 15) // 16) * ((D + 63) // 64) if both_views else 0.0
+        kernel_name = S.dense_kernel_name(rows, cols, words, D, both_views) if variant != "5x5" else S.DOMINANT_KERNEL
+        on_matrix_cores = kernel_name == "dense_wta_mx_kernel"
+        if on_matrix_cores:      # 32 keys per tile of right columns, output row and 32-column block
+            part_bytes = 4.0 * 32 * (5 if D > 64 else 3) * F * (rows - 4) * ((cols - 4 + 31) // 32) if both_views else 0.0
+        else:
+            part_bytes = 4.0 * 80 * F * (rows - 4) * ((cols - 4 + 15) // 16) * ((D + 63) // 64) if both_views else 0.0
         hbm_bytes = float(rows * cols * F * (2 * 4 * words + 4)) + part_bytes
         try:
             measured_peak = ctx.probe_valu_rate(0, 4, 20000) / 1e12
@@ -292,21 +297,23 @@ def main():
         achieved = valu_ops / (k_ms * 1e-3) / 1e12
         traffic = None   # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_w%d%s.json" % (words, "_both" if both_views else ""))))
-            if tj["kernel"] == S.DOMINANT_KERNEL and tj["words"] == words and F == 64 and D == 128:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_w%d%s%s.json" % (words, "_both" if both_views else "",
+                                                                                         "_mx" if on_matrix_cores else ""))))
+            if tj["kernel"] == kernel_name and tj["words"] == words and F == 64 and D == 128:
                 traffic = (tj["fetch_size_kb"] + tj["write_size_kb"]) * 1024.0
         except Exception:
             traffic = None
         roofline = {
             "bound": "valu",
-            "kernel": S.DOMINANT_KERNEL,
+            "kernel": kernel_name,
             "achieved": round(achieved, 3),
             "peak": round(VALU_PEAK_TLOPS, 2),
             "unit": "Tlane-op/s",
             "frac": round(achieved / VALU_PEAK_TLOPS, 4),
             "traffic": traffic,
             "kernel_ms": round(k_ms, 4),
-            "kernel_variant": "both views from one sweep (left map + right view's partial minima)" if both_views else "left view",
+            "kernel_variant": ("both views from one pass over the cost values (left map + the right view's partial %s)"
+                               % ("keys, cost values as fp4 dot products on the matrix cores" if on_matrix_cores else "minima")) if both_views else "left view",
             "launches_per_step": 2 if (lr and not both_views) else 1,
             "algorithmic_ops_per_launch": valu_ops,
             "measured_xor_bcnt_peak": None if measured_peak is None else round(measured_peak, 2),
@@ -318,6 +325,17 @@ def main():
                     "(2 lane-instr per pix*disp per 32-bit descriptor word, aggregation and argmin not counted; "
                     "the both-views kernel is priced on ONE cost volume although it serves two searches)",
         }
+        if on_matrix_cores:
+            # the same launch seen from the matrix pipe: per (left column, right column) pair of a 32 x 32 tile and census
+            # row, 5 k-steps of 64 for the row that enters the window and 5 for the row that leaves it
+            tiles = 5 if D > 64 else 3
+            strips = (rows - 4 + 95) // 96                       # a strip's first five rows have nothing leaving the window yet
+            mfma_count = tiles * (10 * (rows - 4 + 4 * strips) - 25 * strips) * ((cols - 4 + 31) // 32) * F
+            mfma_flops = 2.0 * 32 * 32 * 64 * mfma_count
+            roofline["mfma"] = {"instruction": "v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 operands)", "flops_per_launch": mfma_flops,
+                                "achieved": round(mfma_flops / (k_ms * 1e-3) / 1e12, 1), "peak": 10000.0, "unit": "TFLOP/s",
+                                "frac": round(mfma_flops / (k_ms * 1e-3) / 1e12 / 10000.0, 4),
+                                "note": "issued matrix work (tiles are 32 disparities wider than the search, halo rows included)"}
         if both_views:
             # the single-view sweep beside it (what --variant 9x7 runs, and SVX_LR_TWO_SWEEPS=1 runs twice)
             t1 = S.dominant_kernel_timer(ctx, left, right, D, disp, words)

@@ -21,6 +21,7 @@ from ._lib import (  # noqa: F401
     VIEW_RIGHT,
     EXPORTS,
     DOMINANT_KERNEL,
+    dense_kernel_name,
     dominant_kernel_timer,
     delaunay,
     Mesh,

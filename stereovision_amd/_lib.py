@@ -77,6 +77,7 @@ EXPORTS = {
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
     "svx_probe_both_views_sweep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "svx_dense_wta_matrix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "svx_dense_kernel_choice": (_i, [_i, _i, _i, _i, _i]),
 }
 
 
@@ -724,6 +725,12 @@ def delaunay(pts_xy):
 
 # ---- measurement helpers used by bench.py -------------------------------------------------------
 DOMINANT_KERNEL = "dense_wta5x5_sweep_kernel"
+DENSE_KERNELS = {0: "dense_wta5x5_sweep_kernel", 1: "dense_wta_mx_kernel", 2: "dense_wta5x5_plain_kernel"}
+
+
+def dense_kernel_name(rows, cols, words, max_disp, both_views):
+    """Name of the kernel libsvx runs for the dense search of this size (svx_dense_kernel_choice)."""
+    return DENSE_KERNELS[load_library().svx_dense_kernel_choice(int(rows), int(cols), int(words), int(max_disp), int(bool(both_views)))]
 
 
 def dominant_kernel_timer(ctx, left, right, max_disp, disp, words=1, both_views=False):

@@ -91,6 +91,29 @@ __device__ __forceinline__ float mx_max3(float a, float b, float c) { float r; a
 template <int... Is, class F>
 __device__ __forceinline__ void mx_static_for(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
 
+// Matrix instruction after which staging unit v of the next row is issued.  Units: round g = v / 2 (entering row
+// g < T + 2, then the leaving row), half v & 1 of its expansion in the steady state (PER = 10 instructions per tile);
+// whole rounds before it (PER = 5).  Round g < T holds the right pixels tile g reads (and 4 that tile g - 1 reads),
+// round T the last 4 right pixels and left pixels, round T + 1 left pixels.  The entering row's operands of a tile are
+// all fetched by the tile's first instruction (they are fetched 4 ahead), the leaving row's by its sixth.
+template <int T, bool STEADY>
+constexpr int mx_unit_step(int v) {
+    constexpr int R = T + 2;
+    const int g0 = STEADY ? v / 2 : v, half = STEADY ? v & 1 : 0;
+    const bool old = g0 >= R;
+    const int g = old ? g0 - R : g0;
+    if (STEADY) {
+        if (g == T + 1) return (old ? 3 : 1) + half;
+        if (g == T) return 10 * (T - 1) + (old ? 8 : 1) + half;
+        if (g == T - 1) return 10 * g + (old ? 6 : 3) + half;
+        return 10 * g + (old ? 7 : 5) + half;
+    }
+    if (g == T + 1) return old ? 2 : 1;
+    if (g == T) return 5 * (T - 1) + (old ? 4 : 1);
+    if (g == T - 1) return 5 * g + (old ? 3 : 2);
+    return 5 * g + (old ? 4 : 3);
+}
+
 template <int T>
 struct MxState {
     using G = MxGeom<T>;
@@ -163,14 +186,13 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane) {
 // next row, so tiles 0 .. T-2 are read while later tiles of the same row run and tile T-1 while tile 0 of the next
 // row runs, followed by the lane reduction and the store of that previous row.
 template <int T, bool STEADY, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *__restrict__ cur_n, const uint4 *__restrict__ cur_o,
-                                       uint4 *__restrict__ nxt_n, uint4 *__restrict__ nxt_o, MxState<T> &st,
+__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], uint4 *buf_n, uint4 *buf_o, MxState<T> &st,
                                        const uint32_t *__restrict__ right_new, const uint32_t *__restrict__ right_old,
                                        long off_new, long off_old, int lane, int swap32) {
     using G = MxGeom<T>;
     constexpr int PER = STEADY ? 10 : 5, S = T * PER, P = MX_P, RR = MxState<T>::RR;
     constexpr int UNITS = STEADY ? 4 * G::ROUNDS : 2 * G::ROUNDS;     // staging work in halves of a round, or whole rounds
-    static_assert(S >= UNITS, "one unit of staging work per matrix instruction at most");
+    static_assert(G::ROUNDS == T + 2 && MX_P == 4, "the staging timetable assumes T + 2 rounds and operands fetched 4 ahead");
     static_assert(T >= 3, "the fold schedule needs three tiles");
     const int n = lane & 31, h = lane >> 5;
     uint32_t c22;
@@ -179,12 +201,12 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *__restric
     mx_v8i an[5], ao[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        an[k] = mx_frag(cur_n[h * G::PLANE + G::RPX + n + k]);
-        if (STEADY) ao[k] = mx_frag(cur_o[h * G::PLANE + G::RPX + n + k]);
+        an[k] = mx_frag(buf_n[h * G::PLANE + G::RPX + n + k]);
+        if (STEADY) ao[k] = mx_frag(buf_o[h * G::PLANE + G::RPX + n + k]);
     }
     auto right = [&](int s) -> uint4 {
         const int t = s / PER, j = s % PER, k = j % 5;
-        return (j >= 5 ? cur_o : cur_n)[h * G::PLANE + 32 * t + n + k];
+        return (j >= 5 ? buf_o : buf_n)[h * G::PLANE + 32 * t + n + k];
     };
     uint4 fb[P];
 #pragma unroll
@@ -199,10 +221,12 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *__restric
         acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(j >= 5 ? ao[k] : an[k], b, acc[t], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         asm volatile("" : "+v"(acc[t]));      // keeps the instruction at this place among the ordered statements around it
 
-        // staging of the next row: unit v after matrix instruction v * S / UNITS
+        // staging of the next row into the same buffers (LDS operations of a wavefront execute in order): a round of
+        // right pixels is overwritten once the tile that reads it has issued its reads, the left pixels (read at the
+        // start of the row) at once; mx_unit_step has the timetable
         mx_static_for(std::make_integer_sequence<int, UNITS>{}, [&](auto v_c) __attribute__((always_inline)) {
             constexpr int v = decltype(v_c)::value;
-            if constexpr (v * S / UNITS == s && !(MX_X & 1)) {
+            if constexpr (mx_unit_step<T, STEADY>(v) == s && !(MX_X & 1)) {
                 constexpr int g = STEADY ? v / 2 : v;                 // round: entering row first, then the leaving row
                 constexpr bool old = g >= G::ROUNDS;
                 constexpr int i = old ? g - G::ROUNDS : g;
@@ -217,7 +241,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *__restric
                     e.x = st.hx; e.y = st.hy;
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.z) : "v"(w << 1), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.w) : "v"(w), "s"(m88), "v"(c22));
-                    (old ? nxt_o : nxt_n)[i == G::ROUNDS - 1 ? st.slot_last : st.slot0 + i * 32] = e;
+                    (old ? buf_o : buf_n)[i == G::ROUNDS - 1 ? st.slot_last : st.slot0 + i * 32] = e;
                     if constexpr (i < RR) {
                         if constexpr (old) st.wo[i] = right_old[st.roff[i]]; else st.wn[i] = right_new[st.roff[i]];
                     } else {
@@ -302,7 +326,7 @@ __device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<
 
 // Strip of one x-block: census rows y_lo-2 .. y_hi+1, output rows y_lo .. y_hi-1.
 template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::SLOTS], const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
+__device__ __forceinline__ void mx_strip(uint4 (&lds)[2][MxGeom<T>::SLOTS], const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
                                          int cols, int max_disp, int xl0, int y_lo, int n_rows, int lane, float *__restrict__ disp,
                                          float *__restrict__ part_row0, long part_stride) {
     using G = MxGeom<T>;
@@ -368,7 +392,7 @@ __device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::SLOTS], c
         uint32_t c22;
         asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
 #pragma unroll
-        for (int i = 0; i < G::ROUNDS; ++i) lds[0][0][i == G::ROUNDS - 1 ? st.slot_last : st.slot0 + i * 32] = mx_expand(word(i, 0), c22);
+        for (int i = 0; i < G::ROUNDS; ++i) lds[0][i == G::ROUNDS - 1 ? st.slot_last : st.slot0 + i * 32] = mx_expand(word(i, 0), c22);
 #pragma unroll
         for (int i = 0; i < G::ROUNDS; ++i) { st.wn[i] = word(i, 1); st.wo[i] = 0u; }
     }
@@ -376,15 +400,13 @@ __device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::SLOTS], c
 #pragma unroll 1
     for (int r = 0; r < 5; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)max(r - 3, 0) * row_words;
-        mx_row<T, false, BOTH, EDGE>(acc, lds[r & 1][0], lds[r & 1][1], lds[(r + 1) & 1][0], lds[(r + 1) & 1][1], st,
-                                     cr0 + on, cr0 + oo, on, oo, lane, swap32);
+        mx_row<T, false, BOTH, EDGE>(acc, lds[0], lds[1], st, cr0 + on, cr0 + oo, on, oo, lane, swap32);
     }
     mx_first_output<T, BOTH, EDGE>(acc, st, swap32);
 #pragma unroll 1
     for (int r = 5; r < n_rows; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)(r - 3) * row_words;
-        mx_row<T, true, BOTH, EDGE>(acc, lds[r & 1][0], lds[r & 1][1], lds[(r + 1) & 1][0], lds[(r + 1) & 1][1], st,
-                                    cr0 + on, cr0 + oo, on, oo, lane, swap32);
+        mx_row<T, true, BOTH, EDGE>(acc, lds[0], lds[1], st, cr0 + on, cr0 + oo, on, oo, lane, swap32);
     }
     mx_last_output<T, BOTH, EDGE>(acc, st, lane, swap32);
 }
@@ -395,11 +417,11 @@ __device__ __forceinline__ void mx_strip(uint4 (&lds)[2][2][MxGeom<T>::SLOTS], c
 // BOTH: also stores, for every output row and x-block, the right view's best key of each of the block's 32 T right
 // columns over the block's left columns: partial[frame][row][x-block][32 T] (svx_mx_right_disparity merges them).
 template <int T, bool BOTH>
-__global__ __launch_bounds__(64) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
+__global__ __launch_bounds__(64, 2) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                           int rows, int cols, int max_disp, int strip_rows,
                                                           float *__restrict__ disp_all, int write_border, float *__restrict__ partial) {
     using G = MxGeom<T>;
-    __shared__ uint4 lds[2][2][G::SLOTS];            // [row parity][entering row, leaving row][see MxGeom]
+    __shared__ uint4 lds[2][G::SLOTS];               // [entering row, leaving row][see MxGeom]
     const int lane = threadIdx.x;
     const int n = lane & 31, h = lane >> 5;
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
