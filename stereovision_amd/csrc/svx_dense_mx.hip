@@ -65,19 +65,19 @@ __device__ __forceinline__ mx_v8i mx_frag(const uint4 v) {
 }
 
 // Pieces of the maximum over the 16 lanes of every row for 16 registers at once (lane l ends up with register l & 15);
-// they are issued between the matrix instructions of the following row.
+// they are issued between the matrix instructions of the following row.  A DPP operand must have been written at least
+// two instructions earlier: the pieces carry no padding of their own, their callers keep them apart (MX_DPP_GAP where
+// one piece follows another directly).
+#define MX_DPP_GAP() asm volatile("s_nop 1")
 // stage A, pair i: lanes 0..7 of a row (banks 0,1) keep register i, lanes 8..15 register i + 8
-#define MX_RED_A(i) asm volatile("s_nop 1\n\t"                                                       \
-                                 "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+#define MX_RED_A(i) asm volatile("v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
                                  "v_max_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"     \
                                  : "=&v"(st.ra[i]) : "v"(st.best[i]), "v"(st.best[i + 8]))
 // stage B, pair i: banks 0,2 keep register i (partner lane + 4), banks 1,3 register i + 4 (partner lane - 4)
-#define MX_RED_B(i) asm volatile("s_nop 1\n\t"                                                       \
-                                 "v_max_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
+#define MX_RED_B(i) asm volatile("v_max_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
                                  "v_max_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"     \
                                  : "=&v"(st.rb[i]) : "v"(st.ra[i]), "v"(st.ra[i + 4]))
-#define MX_RED_C() asm volatile("s_nop 1\n\t"                                                                  \
-                                "v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+#define MX_RED_C() asm volatile("v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
                                 "v_max_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
                                 "v_max_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
                                 "v_max_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"      \
@@ -253,24 +253,36 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], uint4 *buf_n, uint4 *b
 
         if constexpr (STEADY && !(MX_X & 2)) {
             // left view
-            if constexpr (t == 0 && j < 8) {                           // last tile of the previous row
-                st.best[2 * j] = mx_max(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, T - 1, 2 * j));
-                st.best[2 * j + 1] = mx_max(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, T - 1, 2 * j + 1));
+            // (five tiles: two three-way maxima per element; fewer tiles: tile by tile)
+            if constexpr (T == 5) {
+                if constexpr (t == 0 && j < 8) {                       // tiles 3 and 4 of the previous row
+                    st.best[2 * j] = mx_max3(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, 3, 2 * j), mx_elem_l<T, EDGE>(acc, st, 4, 2 * j));
+                    st.best[2 * j + 1] = mx_max3(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, 3, 2 * j + 1), mx_elem_l<T, EDGE>(acc, st, 4, 2 * j + 1));
+                }
+                if constexpr (t == 3 && j < 8) {                       // tiles 0, 1 and 2 of this row
+                    st.best[2 * j] = mx_max3(mx_elem_l<T, EDGE>(acc, st, 0, 2 * j), mx_elem_l<T, EDGE>(acc, st, 1, 2 * j), mx_elem_l<T, EDGE>(acc, st, 2, 2 * j));
+                    st.best[2 * j + 1] = mx_max3(mx_elem_l<T, EDGE>(acc, st, 0, 2 * j + 1), mx_elem_l<T, EDGE>(acc, st, 1, 2 * j + 1), mx_elem_l<T, EDGE>(acc, st, 2, 2 * j + 1));
+                }
+            } else {
+                if constexpr (t == 0 && j < 8) {                       // last tile of the previous row
+                    st.best[2 * j] = mx_max(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, T - 1, 2 * j));
+                    st.best[2 * j + 1] = mx_max(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, T - 1, 2 * j + 1));
+                }
+                if constexpr (t == 2 && j >= 5 && j < 9) {             // tiles 0 and 1 of this row
+#pragma unroll
+                    for (int i = 4 * (j - 5); i < 4 * (j - 5) + 4; ++i)
+                        st.best[i] = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
+                }
+                if constexpr (t >= 3 && j < 8) {                       // tile t - 1 of this row
+                    st.best[2 * j] = mx_max(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, t - 1, 2 * j));
+                    st.best[2 * j + 1] = mx_max(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, t - 1, 2 * j + 1));
+                }
             }
             if constexpr (t == 1 && j < 8) { MX_RED_A(j); }
             if constexpr (t == 2 && j == 0) { MX_RED_B(0); MX_RED_B(1); }
             if constexpr (t == 2 && j == 1) { MX_RED_B(2); MX_RED_B(3); }
             if constexpr (t == 2 && j == 2) { MX_RED_C(); }
             if constexpr (t == 2 && j == 3) { mx_reduce_tail<T>(st, lane); st.out += st.out_stride; }
-            if constexpr (t == 2 && j >= 5 && j < 9) {                 // tiles 0 and 1 of this row
-#pragma unroll
-                for (int i = 4 * (j - 5); i < 4 * (j - 5) + 4; ++i)
-                    st.best[i] = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
-            }
-            if constexpr (t >= 3 && j < 8) {                           // tile t - 1 of this row
-                st.best[2 * j] = mx_max(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, t - 1, 2 * j));
-                st.best[2 * j + 1] = mx_max(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, t - 1, 2 * j + 1));
-            }
             // right view: tile t - 1 of this row, or the last tile of the previous row
             if constexpr (BOTH) {
                 constexpr int u = t == 0 ? T - 1 : t - 1;
@@ -293,7 +305,7 @@ __device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState
     for (int i = 0; i < 16; ++i) {
         float b = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
 #pragma unroll
-        for (int u = 2; u < T - 1; ++u) b = mx_max(b, mx_elem_l<T, EDGE>(acc, st, u, i));
+        for (int u = 2; u < (T == 5 ? 3 : T - 1); ++u) b = mx_max(b, mx_elem_l<T, EDGE>(acc, st, u, i));   // the rest follows with the next row
         st.best[i] = b;
     }
     if (BOTH) {
@@ -311,9 +323,15 @@ __device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState
 template <int T, bool BOTH, bool EDGE>
 __device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<T> &st, int lane, int swap32) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, T - 1, i));
+    for (int i = 0; i < 16; ++i) {
+        if (T == 5) st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, 3, i));
+        st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, T - 1, i));
+    }
+    MX_DPP_GAP();
     MX_RED_A(0); MX_RED_A(1); MX_RED_A(2); MX_RED_A(3); MX_RED_A(4); MX_RED_A(5); MX_RED_A(6); MX_RED_A(7);
+    MX_DPP_GAP();
     MX_RED_B(0); MX_RED_B(1); MX_RED_B(2); MX_RED_B(3);
+    MX_DPP_GAP();
     MX_RED_C();
     mx_reduce_tail<T>(st, lane);
     if (BOTH) {
