@@ -25,6 +25,9 @@ typedef float mx_v16f __attribute__((ext_vector_type(16)));
 #ifndef MX_X
 #define MX_X 0      // measurement aid: bit 0 drops the staging work, bit 1 the winner selection (results are wrong then)
 #endif
+#ifndef MX_PLANE_PAD
+#define MX_PLANE_PAD 0      // measurement aid: extra pixels between the two planes of a staged row
+#endif
 #ifndef MX_P
 #define MX_P 4      // right operands fetched this many matrix instructions ahead
 #endif
@@ -42,9 +45,9 @@ struct MxGeom {
     // 256 consecutive bytes (with the two words of a pixel side by side it would hit every bank twice).  The planes
     // are PLANE pixels apart, PLANE = 8 mod 16, so that the 8 + 8 lanes of a write group land in different banks; the
     // lanes of the last staging round that hold no word write behind the planes.
-    static constexpr int PLANE = RPX + LPX;
+    static constexpr int PLANE = RPX + LPX + MX_PLANE_PAD;
     static constexpr int SLOTS = 2 * PLANE + (ROUNDS * 64 - WORDS);
-    static_assert(PLANE % 16 == 8, "plane offset must alternate the bank halves");
+    static_assert(MX_PLANE_PAD != 0 || PLANE % 16 == 8, "plane offset must alternate the bank halves");
 };
 
 // 32 descriptor bits -> 32 fp4 values: dword j holds bits j, j+4, .. j+28 (the same permutation on both operands).
