@@ -287,7 +287,7 @@ def main():
         kernel_name = S.dense_kernel_name(rows, cols, words, D, both_views) if variant != "5x5" else S.DOMINANT_KERNEL
         on_matrix_cores = kernel_name == "dense_wta_mx_kernel"
         if on_matrix_cores:      # 32 keys per tile of right columns, output row and 32-column block
-            part_bytes = 4.0 * 32 * (5 if D > 64 else 3) * F * (rows - 4) * ((cols - 4 + 31) // 32) if both_views else 0.0
+            part_bytes = 4.0 * 32 * (3 if D <= 64 else 5 if D <= 128 else 9) * F * (rows - 4) * ((cols - 4 + 31) // 32) if both_views else 0.0
         else:
             part_bytes = 4.0 * 80 * F * (rows - 4) * ((cols - 4 + 15) // 16) * ((D + 63) // 64) if both_views else 0.0
         hbm_bytes = float(rows * cols * F * (2 * 4 * words + 4)) + part_bytes
@@ -331,7 +331,7 @@ def main():
             # algorithmic work = per pix*disp one 5-column x 64-bit dot product for the census row that enters the 5-row
             # window and one for the row that leaves it = 2 * 5 * 64 multiply-adds = 1280 flop.  The vector-popcount
             # pricing used for the sweep kernel (2 lane-instructions per descriptor word and pix*disp) stays beside it.
-            tiles = 5 if D > 64 else 3
+            tiles = 3 if D <= 64 else 5 if D <= 128 else 9
             strips = (rows - 4 + 95) // 96                       # a strip's first five rows have nothing leaving the window yet
             mfma_count = tiles * (10 * (rows - 4 + 4 * strips) - 25 * strips) * ((cols - 4 + 31) // 32) * F
             issued_flops = 2.0 * 32 * 32 * 64 * mfma_count

@@ -430,12 +430,12 @@ int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left, const 
 /* Which kernel the dense search of this size runs (for benchmarks that name the kernel they time): 0 = the vector
  * sweep, 1 = the matrix-core search, 2 = one thread per pixel.  both_views: the search of svx_dense_wta_both and of the
  * fused left-right entry points.  SVX_MX in the environment (0 = never the matrix cores, 1 = wherever they apply)
- * overrides the default, which uses them for the both-views search on two-word descriptors at up to 128 disparities.
+ * overrides the default, which uses them for the both-views search on two-word descriptors at up to 256 disparities.
  * No counterpart in the reference.  Host only. */
 int svx_dense_kernel_choice(int rows, int cols, int words, int max_disp, int both_views);
 /* The search of svx_dense_wta / svx_dense_wta_both on two-word descriptors with the cost values formed on the matrix
  * cores (fp4 dot products of the expanded descriptors; denseCensusStereo/denseCensusStereo.cpp:87-131 generalised as
- * there): identical results.  Covers cols >= 36, rows >= 5, 1 <= max_disp <= 128 (SVX_ERR_UNSUPPORTED otherwise).
+ * there): identical results.  Covers cols >= 36, rows >= 5, 1 <= max_disp <= 256 (SVX_ERR_UNSUPPORTED otherwise).
  * disp_right may be NULL (left view only).  Border pixels are written as 0.  Asynchronous. */
 int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
                          int max_disp, float *disp_left, float *disp_right);

@@ -969,7 +969,7 @@ static int launch_both_views(svx_ctx *ctx, const uint32_t *cl, const uint32_t *c
                              float *disp_left, float *disp_right, float lr_threshold, int group, uint32_t *partial, bool sweep_only = false) {
     const size_t n = (size_t)rows * cols;
     const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
-    // Two-word descriptors at up to 128 disparities: the cost values are formed on the matrix cores (1.37 ms against
+    // Two-word descriptors at up to 256 disparities: the cost values are formed on the matrix cores (at 128: 1.37 ms against
     // 1.57 ms per 64 KITTI frames, and a cheaper merge); SVX_MX=0 keeps the vector sweep.  The partial keys take half
     // the room of the vector sweep's partial minima, so the buffer sized for those is large enough.
     const bool mx = both_views_on_matrix_cores(rows, cols, words, max_disp);

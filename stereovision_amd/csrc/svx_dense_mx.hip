@@ -33,6 +33,9 @@ typedef float mx_v16f __attribute__((ext_vector_type(16)));
 #endif
 constexpr int MX_M = 32;                 // left columns per wavefront
 constexpr int MX_MAX_STRIP = 96;
+#ifndef MX_MAX_DISP
+#define MX_MAX_DISP 256   // 3, 5 or 9 tiles of 32 right columns
+#endif
 
 template <int T>
 struct MxGeom {
@@ -438,7 +441,7 @@ __device__ __forceinline__ void mx_strip(uint4 (&lds)[2][MxGeom<T>::SLOTS], cons
 // BOTH: also stores, for every output row and x-block, the right view's best key of each of the block's 32 T right
 // columns over the block's left columns: partial[frame][row][x-block][32 T] (svx_mx_right_disparity merges them).
 template <int T, bool BOTH>
-__global__ __launch_bounds__(64, 2) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
+__global__ __launch_bounds__(64, T <= 5 ? 2 : 1) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                           int rows, int cols, int max_disp, int strip_rows,
                                                           float *__restrict__ disp_all, int write_border, float *__restrict__ partial) {
     using G = MxGeom<T>;
@@ -520,9 +523,9 @@ __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl
     if (fabsf(svx_mx_right_disparity<T>(prow, xr, cols, n_xblocks) - d1) > threshold) dl[x] = invalid;
 }
 
-bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX_M + 4 && rows >= 5 && max_disp >= 1 && max_disp <= 128; }
+bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX_M + 4 && rows >= 5 && max_disp >= 1 && max_disp <= MX_MAX_DISP; }
 
-static int mx_tiles(int max_disp) { return max_disp <= 64 ? 3 : 5; }
+static int mx_tiles(int max_disp) { return max_disp <= 64 ? 3 : max_disp <= 128 ? 5 : 9; }
 static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }
 
 size_t svx_mx_partial_words(int rows, int cols, int n_frames, int max_disp) {
@@ -537,7 +540,9 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     const int n_strips = (rows - 4 + strip_rows - 1) / strip_rows;
     dim3 grid(mx_xblocks(cols), n_strips, n_frames);
     const int T = mx_tiles(max_disp);
-    if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
+    if (T == 9 && !partial) dense_wta_mx_kernel<9, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
+    else if (T == 9) dense_wta_mx_kernel<9, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
+    else if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
     else if (T == 3) dense_wta_mx_kernel<3, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
     else if (!partial) dense_wta_mx_kernel<5, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
     else dense_wta_mx_kernel<5, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
@@ -551,7 +556,10 @@ int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, 
                         float *disp_left, float *disp_right, float lr_threshold) {
     const dim3 grid(svx_cdiv(cols, 256), rows, n_frames);
     const int nb = mx_xblocks(cols);
-    if (mx_tiles(max_disp) == 3) {
+    if (mx_tiles(max_disp) == 9) {
+        if (disp_right) mx_right_view_merge_kernel<9><<<grid, 256, 0, ctx->stream>>>(partial, rows, cols, nb, disp_right);
+        else mx_lr_check_kernel<9><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, rows, cols, nb, lr_threshold, -1.0f);
+    } else if (mx_tiles(max_disp) == 3) {
         if (disp_right) mx_right_view_merge_kernel<3><<<grid, 256, 0, ctx->stream>>>(partial, rows, cols, nb, disp_right);
         else mx_lr_check_kernel<3><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, rows, cols, nb, lr_threshold, -1.0f);
     } else {
@@ -572,7 +580,7 @@ SVX_API int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, cons
     SVX_REQUIRE(ctx, census_left && census_right && disp_left, SVX_ERR_INVALID_ARG, "svx_dense_wta_matrix: null pointer");
     SVX_REQUIRE(ctx, n_frames >= 1 && n_frames <= 65535 && rows <= 65535, SVX_ERR_INVALID_ARG, "svx_dense_wta_matrix: bad frame count or size");
     SVX_REQUIRE(ctx, svx_mx_sweep_eligible(rows, cols, max_disp), SVX_ERR_UNSUPPORTED,
-                "svx_dense_wta_matrix: needs cols >= 36, rows >= 5, 1 <= max_disp <= 128");
+                "svx_dense_wta_matrix: needs cols >= 36, rows >= 5, 1 <= max_disp <= 256");
     if (!disp_right) return svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, nullptr);
     const size_t per_frame = svx_mx_partial_words(rows, cols, 1, max_disp);
     SVX_REQUIRE(ctx, per_frame * n_frames * sizeof(float) <= ((size_t)4 << 30), SVX_ERR_UNSUPPORTED, "svx_dense_wta_matrix: batch too large for one call");

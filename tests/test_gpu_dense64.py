@@ -74,7 +74,7 @@ def test_dense_wta_both_views_from_one_sweep(ctx, rows, cols, max_disp, words):
 
 
 @pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (12, 40, 64), (30, 150, 128), (5, 36, 1), (110, 90, 70), (9, 300, 100),
-                                                 (101, 37, 33), (7, 200, 128), (40, 133, 65)])
+                                                 (101, 37, 33), (7, 200, 128), (40, 133, 65), (20, 300, 200), (12, 400, 256), (9, 290, 129)])
 def test_dense_wta_matrix_matches_oracle(ctx, rows, cols, max_disp):
     """The matrix-core form: both views bit for bit, on descriptors with few distinct values (many cost ties)."""
     rng = np.random.default_rng(rows * 1000 + cols + max_disp)
@@ -98,7 +98,7 @@ def test_dense_wta_matrix_refuses_what_it_does_not_cover(ctx):
         ctx.dense_wta_matrix(cl, cl, 16)
     cl = dev_u32(np.zeros((1, 8, 64, 2), np.uint32))
     with pytest.raises(S.SvxError):
-        ctx.dense_wta_matrix(cl, cl, 129)
+        ctx.dense_wta_matrix(cl, cl, 257)
 
 
 def test_left_view_one_word_is_the_reference_search(ctx):
