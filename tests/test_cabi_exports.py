@@ -38,3 +38,17 @@ def test_no_gpu_means_loud_failure():
             assert e.code == -5
         else:
             raise AssertionError("Context() must raise without a GPU")
+
+
+def test_dense_kernel_choice_is_a_host_side_query():
+    """svx_dense_kernel_choice names the kernel a size runs (0 vector sweep, 1 matrix cores, 2 one thread per pixel)."""
+    if os.environ.get("SVX_MX") is not None:
+        return                                              # the tuning knob overrides the defaults checked here
+    lib = S.load_library()
+    assert lib.svx_dense_kernel_choice(368, 1232, 2, 128, 1) == 1      # both views, two-word descriptors: matrix cores
+    assert lib.svx_dense_kernel_choice(1072, 1920, 2, 256, 1) == 1
+    assert lib.svx_dense_kernel_choice(2160, 3840, 2, 512, 1) == 0     # more than 256 disparities: vector sweep
+    assert lib.svx_dense_kernel_choice(368, 1232, 1, 128, 1) == 0      # one-word descriptors
+    assert lib.svx_dense_kernel_choice(368, 1232, 2, 128, 0) == 0      # single view
+    assert lib.svx_dense_kernel_choice(4, 1232, 2, 128, 0) == 2
+    assert S.dense_kernel_name(368, 1232, 2, 128, True) == "dense_wta_mx_kernel"
