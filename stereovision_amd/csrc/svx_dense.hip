@@ -645,11 +645,11 @@ __device__ __forceinline__ uint32_t c97_pair(const uint32_t (&r)[3]) {
 // 16-bit-per-pixel accumulators by a shift and a masked or: three instructions per two comparisons.
 template <bool ALIGNED>
 __device__ __forceinline__ void census9x7_tile_packed(const uint8_t *__restrict__ img_all, int rows, int cols, long total_bytes,
-                                                      uint32_t *__restrict__ out_all) {
+                                                      uint32_t *__restrict__ out_all, int frame) {
     __shared__ uint32_t tile[(C97T_H + 6) * C97T_LROW];
     const long n = (long)rows * cols;
-    const uint8_t *img = img_all + (long)blockIdx.z * n;
-    uint32_t *out = out_all + (long)blockIdx.z * n * 2;
+    const uint8_t *img = img_all + (long)frame * n;
+    uint32_t *out = out_all + (long)frame * n * 2;
     const int x0 = blockIdx.x * C97T_W, y0 = blockIdx.y * C97T_H;
     for (int i = threadIdx.x; i < (C97T_H + 6) * C97T_LROW; i += 256) {
         const int r = i / C97T_LROW, k = i - r * C97T_LROW;
@@ -658,7 +658,7 @@ __device__ __forceinline__ void census9x7_tile_packed(const uint8_t *__restrict_
         if (ALIGNED) {
             if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = *reinterpret_cast<const uint32_t *>(img + (long)gy * cols + gx);
         } else if (gy >= 0 && gy < rows && gx > -4 && gx < cols) {
-            const long a = (long)blockIdx.z * n + (long)gy * cols + gx;         // byte offset in the batch, may be negative by < 4
+            const long a = (long)frame * n + (long)gy * cols + gx;         // byte offset in the batch, may be negative by < 4
             const long a0 = a & ~3L;
             if (a0 >= 0 && a0 + 8 <= total_bytes) {
                 const uint32_t d0 = *reinterpret_cast<const uint32_t *>(img_all + a0), d1 = *reinterpret_cast<const uint32_t *>(img_all + a0 + 4);
@@ -748,10 +748,19 @@ __device__ __forceinline__ void census9x7_tile_packed(const uint8_t *__restrict_
     }
 }
 
+// Both images of a batch of pairs in one launch: grid z = 2 x frames, the first half is the left batch.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void census9x7_pair_kernel(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right, int rows, int cols,
+                                                             long total_bytes, uint32_t *__restrict__ out_left, uint32_t *__restrict__ out_right, int n_frames) {
+    const int z = blockIdx.z;
+    if (z < n_frames) census9x7_tile_packed<ALIGNED>(left, rows, cols, total_bytes, out_left, z);
+    else census9x7_tile_packed<ALIGNED>(right, rows, cols, total_bytes, out_right, z - n_frames);
+}
+
 template <bool ALIGNED, bool PACKED>
 __global__ __launch_bounds__(256) void census9x7_tile_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, long total_bytes,
                                                              uint32_t *__restrict__ out_all) {
-    if (PACKED) { census9x7_tile_packed<ALIGNED>(img_all, rows, cols, total_bytes, out_all); return; }
+    if (PACKED) { census9x7_tile_packed<ALIGNED>(img_all, rows, cols, total_bytes, out_all, blockIdx.z); return; }
     __shared__ uint32_t tile[(C97T_H + 6) * C97T_LROW];
     const long n = (long)rows * cols;
     const uint8_t *img = img_all + (long)blockIdx.z * n;
@@ -842,6 +851,22 @@ SVX_API int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census,
         census9x7_pixel_kernel<<<dim3(svx_cdiv(cols, C97_W), svx_cdiv(rows, C97_H), n_frames), 256, 0, ctx->stream>>>(img, rows, cols, (uint2 *)census);
         SVX_LAUNCH_CHECK(ctx, "census9x7_pixel_kernel");
     }
+    return SVX_OK;
+}
+
+// svx_census9x7_u8 of both images of a batch of pairs, in one launch where the tile kernel applies.
+static int census9x7_pair(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, uint32_t *cl, uint32_t *cr, int rows, int cols, int n_frames) {
+    const bool fast = (((uintptr_t)left & 3u) == 0) && (((uintptr_t)right & 3u) == 0) && (((uintptr_t)cl & 15u) == 0) && (((uintptr_t)cr & 15u) == 0);
+    static const int packed = [] { const char *e = getenv("SVX_CENSUS97_PACKED"); return e ? atoi(e) : 1; }();
+    if (!fast || !packed || cols < 9 || 2 * n_frames > 65535 || svx_cdiv(rows, C97T_H) > 65535) {
+        const int rc = svx_census9x7_u8(ctx, left, cl, rows, cols, n_frames);
+        return rc ? rc : svx_census9x7_u8(ctx, right, cr, rows, cols, n_frames);
+    }
+    const long total_bytes = (long)rows * cols * n_frames;
+    const dim3 grid(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97T_H), 2 * n_frames);
+    if (cols % 4 == 0) census9x7_pair_kernel<true><<<grid, 256, 0, ctx->stream>>>(left, right, rows, cols, total_bytes, cl, cr, n_frames);
+    else census9x7_pair_kernel<false><<<grid, 256, 0, ctx->stream>>>(left, right, rows, cols, total_bytes, cl, cr, n_frames);
+    SVX_LAUNCH_CHECK(ctx, "census9x7_pair_kernel");
     return SVX_OK;
 }
 
@@ -1069,9 +1094,7 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     if (rc) return rc;
     uint32_t *cl = (uint32_t *)ws, *cr = cl + 2 * n, *partial = cr + 2 * n;
     float *dr = (float *)(partial + part_words);
-    rc = svx_census9x7_u8(ctx, left, cl, rows, cols, n_frames);
-    if (rc) return rc;
-    rc = svx_census9x7_u8(ctx, right, cr, rows, cols, n_frames);
+    rc = census9x7_pair(ctx, left, right, cl, cr, rows, cols, n_frames);
     if (rc) return rc;
     if (both) {
         // one sweep; the check reads the right view's partial minima directly (no right disparity map is formed)
