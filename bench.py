@@ -332,7 +332,13 @@ def main():
             # window and one for the row that leaves it = 2 * 5 * 64 multiply-adds = 1280 flop.  The vector-popcount
             # pricing used for the sweep kernel (2 lane-instructions per descriptor word and pix*disp) stays beside it.
             tiles = 3 if D <= 64 else 5 if D <= 128 else 9
-            strips = (rows - 4 + 95) // 96                       # a strip's first five rows have nothing leaving the window yet
+            # strips as svx_launch_mx_sweep chooses them (a strip's first five rows have nothing leaving the window yet)
+            slots = torch.cuda.get_device_properties(dev).multi_processor_count * (8 if tiles <= 5 else 4)
+            per_strip = ((cols - 4 + 31) // 32) * F
+            cost = lambda k: -(-per_strip * k // slots) * (-(-(rows - 4) // k) + 6)
+            k_best = min(range(1, min(16, rows - 4) + 1), key=lambda k: (cost(k), k))
+            strip_rows = -(-(rows - 4) // k_best)
+            strips = -(-(rows - 4) // strip_rows)
             mfma_count = tiles * (10 * (rows - 4 + 4 * strips) - 25 * strips) * ((cols - 4 + 31) // 32) * F
             issued_flops = 2.0 * 32 * 32 * 64 * mfma_count
             alg_flops = 1280.0 * pixdisp_per_frame * F

@@ -32,7 +32,6 @@ typedef float mx_v16f __attribute__((ext_vector_type(16)));
 #define MX_P 4      // right operands fetched this many matrix instructions ahead
 #endif
 constexpr int MX_M = 32;                 // left columns per wavefront
-constexpr int MX_MAX_STRIP = 96;
 #ifndef MX_MAX_DISP
 #define MX_MAX_DISP 256   // 3, 5 or 9 tiles of 32 right columns
 #endif
@@ -536,10 +535,26 @@ size_t svx_mx_partial_words(int rows, int cols, int n_frames, int max_disp) {
 // partial != nullptr: also the right view's partial keys (svx_mx_partial_words floats).
 int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
                         float *disparity, int write_border, float *partial) {
-    const int strip_rows = MX_MAX_STRIP;
-    const int n_strips = (rows - 4 + strip_rows - 1) / strip_rows;
-    dim3 grid(mx_xblocks(cols), n_strips, n_frames);
     const int T = mx_tiles(max_disp);
+    // Strips: every strip re-reads 4 halo rows and starts with 5 rows that fill the window, but the grid should fill the
+    // chip a whole number of times (one wavefront per block; 8 or, with nine tiles, 4 of them fit a CU): take the
+    // number of strips with the smallest (rounds of wavefronts) x (rows a wavefront walks).
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+    const long slots = (long)cus * (T <= 5 ? 8 : 4), per_strip = (long)mx_xblocks(cols) * n_frames;
+    const int out_rows = rows - 4;
+    int n_strips = 1;
+    long best_cost = -1;
+    for (int k = 1; k <= 16 && k <= out_rows; ++k) {
+        const long rounds = (per_strip * k + slots - 1) / slots;
+        const long cost = rounds * ((out_rows + k - 1) / k + 4 + 2);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; n_strips = k; }
+    }
+    // Tuning knob: SVX_MX_STRIP_ROWS forces the output rows per strip.
+    static const int forced_rows = [] { const char *e = getenv("SVX_MX_STRIP_ROWS"); return e ? atoi(e) : 0; }();
+    const int strip_rows = forced_rows > 0 ? forced_rows : (out_rows + n_strips - 1) / n_strips;
+    n_strips = (out_rows + strip_rows - 1) / strip_rows;
+    dim3 grid(mx_xblocks(cols), n_strips, n_frames);
     if (T == 9 && !partial) dense_wta_mx_kernel<9, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
     else if (T == 9) dense_wta_mx_kernel<9, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
     else if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
