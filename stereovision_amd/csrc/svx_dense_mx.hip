@@ -33,7 +33,7 @@ typedef float mx_v16f __attribute__((ext_vector_type(16)));
 #endif
 constexpr int MX_M = 32;                 // left columns per wavefront
 #ifndef MX_MAX_DISP
-#define MX_MAX_DISP 256   // 3, 5 or 9 tiles of 32 right columns
+#define MX_MAX_DISP 256   // 3, 5 or 9 tiles of 32 right columns (17 tiles for 512 disparities spill: 27.5 against 13.3 ms at 4K)
 #endif
 
 template <int T>
@@ -71,18 +71,21 @@ __device__ __forceinline__ mx_v8i mx_frag(const uint4 v) {
 
 // Pieces of the maximum over the 16 lanes of every row for 16 registers at once (lane l ends up with register l & 15);
 // they are issued between the matrix instructions of the following row.  A DPP operand must have been written at least
-// two instructions earlier: the pieces carry no padding of their own, their callers keep them apart (MX_DPP_GAP where
-// one piece follows another directly).
+// two instructions earlier, and the compiler may place a register copy or reload right in front of an asm block: every
+// piece starts with its own padding (measured: no cost).
 #define MX_DPP_GAP() asm volatile("s_nop 1")
 // stage A, pair i: lanes 0..7 of a row (banks 0,1) keep register i, lanes 8..15 register i + 8
-#define MX_RED_A(i) asm volatile("v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+#define MX_RED_A(i) asm volatile("s_nop 1\n\t"                                                       \
+                                 "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
                                  "v_max_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"     \
                                  : "=&v"(st.ra[i]) : "v"(st.best[i]), "v"(st.best[i + 8]))
 // stage B, pair i: banks 0,2 keep register i (partner lane + 4), banks 1,3 register i + 4 (partner lane - 4)
-#define MX_RED_B(i) asm volatile("v_max_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
+#define MX_RED_B(i) asm volatile("s_nop 1\n\t"                                                       \
+                                 "v_max_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
                                  "v_max_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"     \
                                  : "=&v"(st.rb[i]) : "v"(st.ra[i]), "v"(st.ra[i + 4]))
-#define MX_RED_C() asm volatile("v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+#define MX_RED_C() asm volatile("s_nop 1\n\t"                                                                  \
+                                "v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
                                 "v_max_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
                                 "v_max_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
                                 "v_max_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"      \
