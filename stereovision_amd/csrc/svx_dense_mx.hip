@@ -488,6 +488,13 @@ template <int T>
 __device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, int xr, int cols, int n_xblocks) {
     float best = -1048576.0f;
     const int b_first = max((xr - 31 - 2 + MX_M - 1) / MX_M, 0);       // smallest b with 2 + 32 b >= xr - 31
+    if (xr >= 2 && b_first + T - 1 < n_xblocks - 1) {
+        // all regular blocks (xl0 = 2 + 32 b): exactly T of them reach xr, block b_first + k in slot ((xr - 2) & 31) + 32 (T - 1 - k)
+        const float *p = prow + (long)b_first * (32 * T) + ((xr - 2) & 31) + 32 * (T - 1);
+#pragma unroll
+        for (int k = 0; k < T; ++k) best = fmaxf(best, p[k * (32 * T - 32)]);
+        return mx_decode(best);
+    }
 #pragma unroll
     for (int k = 0; k < T + 1; ++k) {
         const int b = min(b_first + k, n_xblocks - 1);
