@@ -187,8 +187,9 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane) {
     *st.out = mx_decode(mx_max(z, zo));                      // lanes l and l ^ 16 write the same value to the same place
 }
 
-// One census row r.  Its operands are in `cur` (staged while the previous row ran).  Between its matrix instructions
-// the wavefront stages row r+1 into `nxt` and fetches the words of row r+2 and, in the steady state (STEADY: the row
+// One census row r.  Its operands are in buf_n / buf_o (staged while the previous row ran).  Between its matrix
+// instructions the wavefront stages row r+1 into the same buffers, behind the reads of row r (mx_unit_step), fetches the
+// words of row r+2 and, in the steady state (STEADY: the row
 // five rows up leaves the window, its products with the left operand negated are added too, and every row has an
 // output), picks the winners: a tile's accumulators are final from its last product until its first product of the
 // next row, so tiles 0 .. T-2 are read while later tiles of the same row run and tile T-1 while tile 0 of the next
