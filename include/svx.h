@@ -51,9 +51,29 @@ typedef struct svx_ctx svx_ctx;
 /* ---- context ---------------------------------------------------------- */
 int svx_create(int device, svx_ctx **out);
 int svx_destroy(svx_ctx *ctx);
-/* hip_stream is a hipStream_t (NULL = the default stream). */
+/* hip_stream is a hipStream_t (NULL = the default stream).  A context works on ONE stream at a time: its
+ * workspace is shared by all its calls, so switching streams first waits for the work queued on the old one.
+ * Callers that want concurrent streams create one context per stream. */
 int svx_set_stream(svx_ctx *ctx, void *hip_stream);
 int svx_synchronize(svx_ctx *ctx);
+/* Per-context tuning options (no counterpart in the reference).  Results never depend on them, only the choice of
+ * kernel.  A new context starts from the built-in defaults, or from the environment variable named below when it is
+ * set at svx_create time; svx_set_option overrides it for that context only.
+ *   SVX_OPT_MATRIX_CORES     (SVX_MX)              -1 = matrix-core search where it is the faster kernel (default),
+ *                                                  0 = never, 1 = wherever it applies
+ *   SVX_OPT_LR_TWO_SWEEPS    (SVX_LR_TWO_SWEEPS)   1 = the left-right entry points search each view with its own sweep
+ *   SVX_OPT_SWEEP_WAVES      (SVX_SWEEP_OCC)       2 or 3 wavefronts per SIMD for the vector sweep (default 3)
+ *   SVX_OPT_SWEEP_WAVES_BOTH (SVX_SWEEP_OCC_BOTH)  the same for the both-views vector sweep
+ *   SVX_OPT_CENSUS97_PACKED  (SVX_CENSUS97_PACKED) 0 = one comparison per instruction in the 9x7 census tile kernel
+ *   SVX_OPT_MX_STRIP_ROWS    (SVX_MX_STRIP_ROWS)   > 0 forces the output rows per strip of the matrix-core search
+ *   SVX_OPT_STAGE_TIMES      (SVX_STAGE_TIMES)     1 = svx_high_perf_stereo synchronises at its stage marks and fills
+ *                                                  svx_pipeline_stage_times (default 0: no synchronisation, times 0) */
+enum svx_option {
+    SVX_OPT_MATRIX_CORES = 0, SVX_OPT_LR_TWO_SWEEPS = 1, SVX_OPT_SWEEP_WAVES = 2, SVX_OPT_SWEEP_WAVES_BOTH = 3,
+    SVX_OPT_CENSUS97_PACKED = 4, SVX_OPT_MX_STRIP_ROWS = 5, SVX_OPT_STAGE_TIMES = 6, SVX_OPT_COUNT = 7
+};
+int svx_set_option(svx_ctx *ctx, int option, int value);
+int svx_get_option(const svx_ctx *ctx, int option, int *value);   /* ctx NULL: the default a new context would get */
 int svx_version(void);
 const char *svx_strerror(int status);
 const char *svx_last_error(const svx_ctx *ctx);
@@ -126,8 +146,10 @@ int svx_sparse_match(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *
  * disparity d in [0, min(max_disp-1, x-5)], strict '<' (ties -> smallest d).
  * svx_dense_wta5x5 writes pixels 2<=x<cols-2, 2<=y<rows-2 only (as the
  * reference does).  svx_dense_census_wta_u8 is the fused hot path: a1 + a2 on
- * both images and a8, no census image or cost volume in HBM; it writes the
- * whole frame (0 outside the interior, the reference's initial value). */
+ * both images and a8 in one call.  The two census batches (4 bytes a pixel and
+ * image) live in the context's workspace between the census and the search
+ * launches; a cost volume never exists.  It writes the whole frame (0 outside
+ * the interior, the reference's initial value). */
 int svx_dense_wta5x5(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right,
                      int rows, int cols, int n_frames, int max_disp, float *disparity);
 int svx_dense_census_wta_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right,
@@ -208,7 +230,8 @@ int svx_plane_prior_raster(svx_ctx *ctx, const int32_t *tri_xy, const float *tri
  *   of right pixel x-d at disparity d, so one sweep over the cost values serves both views: the results are identical
  *   to the two svx_dense_wta calls.
  * svx_lr_check: for 2 <= x < cols-2, 2 <= y < rows-2: d = disp_left(y,x), x_r = x - (int)d;
- *   disp_left(y,x) = invalid_value when x_r < 2 or |disp_right(y,x_r) - d| > threshold.
+ *   disp_left(y,x) = invalid_value when d is no disparity (d < 0, NaN or d >= cols: nothing is read then), when
+ *   x_r < 2, or when |disp_right(y,x_r) - d| > threshold.
  * svx_dense_census9x7_lr_u8: census of both images, left-view search, and for
  *   lr_threshold >= 0 the right-view search and the check (invalid = -1). */
 enum svx_view { SVX_VIEW_LEFT = 0, SVX_VIEW_RIGHT = 1 };
@@ -427,12 +450,12 @@ int svx_probe_valu_rate(svx_ctx *ctx, int mode, int waves_per_simd, int iters, d
  * that a benchmark can bracket it with stream events.  Asynchronous. */
 int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
                                int n_frames, int words, int max_disp, float *disp_left);
-/* Which kernel the dense search of this size runs (for benchmarks that name the kernel they time): 0 = the vector
- * sweep, 1 = the matrix-core search, 2 = one thread per pixel.  both_views: the search of svx_dense_wta_both and of the
- * fused left-right entry points.  SVX_MX in the environment (0 = never the matrix cores, 1 = wherever they apply)
- * overrides the default, which uses them for the both-views search on two-word descriptors at up to 256 disparities.
- * No counterpart in the reference.  Host only. */
-int svx_dense_kernel_choice(int rows, int cols, int words, int max_disp, int both_views);
+/* Which kernel the dense search of this size runs in this context (for benchmarks that name the kernel they time):
+ * 0 = the vector sweep, 1 = the matrix-core search, 2 = one thread per pixel.  both_views: the search of
+ * svx_dense_wta_both and of the fused left-right entry points.  Follows SVX_OPT_MATRIX_CORES; the default uses the
+ * matrix cores for the both-views search on two-word descriptors at up to 256 disparities.  ctx NULL: the choice of a
+ * new context.  No counterpart in the reference.  Host only. */
+int svx_dense_kernel_choice(const svx_ctx *ctx, int rows, int cols, int words, int max_disp, int both_views);
 /* The search of svx_dense_wta / svx_dense_wta_both on two-word descriptors with the cost values formed on the matrix
  * cores (fp4 dot products of the expanded descriptors; denseCensusStereo/denseCensusStereo.cpp:87-131 generalised as
  * there): identical results.  Covers cols >= 36, rows >= 5, 1 <= max_disp <= 256 (SVX_ERR_UNSUPPORTED otherwise).

@@ -1115,6 +1115,8 @@ ORC_API void orc_lr_check(float *dl, const float *dr, int rows, int cols, float 
     for (int y = 2; y < rows - 2; ++y)
         for (int x = 2; x < cols - 2; ++x) {
             const float d = dl[(long)y * cols + x];
+            /* a value that is no disparity (negative, e.g. an earlier pass's invalid marker, NaN, beyond the row) is invalid and reads nothing */
+            if (!(d >= 0.0f) || !(d < (float)cols)) { dl[(long)y * cols + x] = invalid; continue; }
             const int xr = x - (int)d;
             if (xr < 2 || fabsf(dr[(long)y * cols + xr] - d) > threshold) dl[(long)y * cols + x] = invalid;
         }
@@ -1132,8 +1134,9 @@ ORC_API void orc_subpixel_refine(const uint32_t *cl, const uint32_t *cr, int row
     for (int y = 2; y < rows - 2; ++y)
         for (int x = 2; x < cols - 2; ++x) {
             const float f = disp[(long)y * cols + x];
+            if (!(f >= 1.0f) || !(f < (float)maxDisp)) continue;          /* also NaN and values no int can hold */
             const int d = (int)f;
-            if (!(f >= 1.0f) || (float)d != f || d + 1 > maxDisp - 1 || x - (d + 1) < 5) continue;
+            if ((float)d != f || d + 1 > maxDisp - 1 || x - (d + 1) < 5) continue;
             int c[3];
             for (int k = 0; k < 3; ++k) {
                 const int xr = x - (d - 1 + k);

@@ -19,6 +19,13 @@ from ._lib import (  # noqa: F401
     EXFAST_THRESHOLD_ROUND_SAT,
     VIEW_LEFT,
     VIEW_RIGHT,
+    OPT_MATRIX_CORES,
+    OPT_LR_TWO_SWEEPS,
+    OPT_SWEEP_WAVES,
+    OPT_SWEEP_WAVES_BOTH,
+    OPT_CENSUS97_PACKED,
+    OPT_MX_STRIP_ROWS,
+    OPT_STAGE_TIMES,
     EXPORTS,
     DOMINANT_KERNEL,
     dense_kernel_name,

@@ -9,6 +9,8 @@ CENSUS_SSE24, CENSUS_GENERIC25, CENSUS_ZERO_REST = 0, 1, 16
 EXFAST_NONMAX, EXFAST_THRESHOLD_ROUND_SAT = 1, 2
 VIEW_LEFT, VIEW_RIGHT = 0, 1
 WINDOW_5X6, WINDOW_5X5 = 0, 1
+# svx_option of include/svx.h
+OPT_MATRIX_CORES, OPT_LR_TWO_SWEEPS, OPT_SWEEP_WAVES, OPT_SWEEP_WAVES_BOTH, OPT_CENSUS97_PACKED, OPT_MX_STRIP_ROWS, OPT_STAGE_TIMES = range(7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _vp = C.c_void_p
@@ -77,7 +79,9 @@ EXPORTS = {
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
     "svx_probe_both_views_sweep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "svx_dense_wta_matrix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "svx_dense_kernel_choice": (_i, [_i, _i, _i, _i, _i]),
+    "svx_dense_kernel_choice": (_i, [_vp, _i, _i, _i, _i, _i]),
+    "svx_set_option": (_i, [_vp, _i, _i]),
+    "svx_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
 }
 
 
@@ -161,7 +165,8 @@ def _frames(t):
 
 
 class Context:
-    """One libsvx context on one device; work is enqueued on torch's current stream of that device."""
+    """One libsvx context on one device.  Work is enqueued on the stream bound by bind_stream(): torch's current stream
+    of that device at construction, until bind_stream() is called again (a context works on one stream at a time)."""
 
     def __init__(self, device=0):
         import torch
@@ -178,6 +183,16 @@ class Context:
     def bind_stream(self, stream=None):
         s = stream if stream is not None else self._torch.cuda.current_stream(self.device)
         self._call("svx_set_stream", _vp(s.cuda_stream))
+
+    def set_option(self, option, value):
+        self._call("svx_set_option", int(option), int(value))
+
+    def get_option(self, option):
+        v = _i(0)
+        rc = self._lib.svx_get_option(self._h, int(option), C.byref(v))
+        if rc != 0:
+            raise SvxError(rc, self._lib.svx_strerror(rc).decode())
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -728,9 +743,10 @@ DOMINANT_KERNEL = "dense_wta5x5_sweep_kernel"
 DENSE_KERNELS = {0: "dense_wta5x5_sweep_kernel", 1: "dense_wta_mx_kernel", 2: "dense_wta5x5_plain_kernel"}
 
 
-def dense_kernel_name(rows, cols, words, max_disp, both_views):
-    """Name of the kernel libsvx runs for the dense search of this size (svx_dense_kernel_choice)."""
-    return DENSE_KERNELS[load_library().svx_dense_kernel_choice(int(rows), int(cols), int(words), int(max_disp), int(bool(both_views)))]
+def dense_kernel_name(rows, cols, words, max_disp, both_views, ctx=None):
+    """Name of the kernel libsvx runs for the dense search of this size in `ctx` (None: in a new context)."""
+    h = ctx._h if ctx is not None else None
+    return DENSE_KERNELS[load_library().svx_dense_kernel_choice(h, int(rows), int(cols), int(words), int(max_disp), int(bool(both_views)))]
 
 
 def dominant_kernel_timer(ctx, left, right, max_disp, disp, words=1, both_views=False):

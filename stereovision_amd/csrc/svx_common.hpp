@@ -16,7 +16,19 @@ struct svx_ctx {
     size_t pinned_bytes;
     char err[256];
     double stage_ms[SVX_PIPELINE_STAGES];   // wall-clock per stage of the last svx_high_perf_stereo call
+    int opt[SVX_OPT_COUNT];                 // svx_set_option values (defaults: svx_option_default)
+    void *arena;                            // svx_high_perf_stereo's device images, kept between calls and grown on demand
+    size_t arena_bytes;
+    void *tri;                              // triangle corners and planes of the mesh prior, kept between calls
+    size_t tri_bytes;
+    hipEvent_t pinned_read;                 // recorded behind the last asynchronous copy out of `pinned`
+    bool pinned_busy;
 };
+
+// Default of an option: its environment variable when set, else the built-in value.
+int svx_option_default(int option);
+// Option value of a context (nullptr: the defaults).
+inline int svx_opt(const svx_ctx *ctx, int option) { return ctx ? ctx->opt[option] : svx_option_default(option); }
 
 #define SVX_API extern "C" __attribute__((visibility("default")))
 
@@ -52,6 +64,10 @@ inline int svx_fail(svx_ctx *ctx, int code, const char *fmt, ...) {
 // Makes the context's device current and returns its workspace grown to at least `bytes`.
 int svx_ws_reserve(svx_ctx *ctx, size_t bytes, void **out);
 int svx_pinned_reserve(svx_ctx *ctx, size_t bytes, void **out);
+// After enqueueing an asynchronous copy out of the pinned buffer: the next svx_pinned_reserve waits for it.
+int svx_pinned_mark_read(svx_ctx *ctx);
+// Grows a device block kept in the context (pointer and size fields passed in) to at least `bytes`.
+int svx_block_reserve(svx_ctx *ctx, void **block, size_t *block_bytes, size_t bytes, const char *what);
 int svx_enter(svx_ctx *ctx);
 
 // Matrix-core form of the dense search on two-word descriptors (svx_dense_mx.hip).

@@ -25,7 +25,31 @@ int svx_ws_reserve(svx_ctx *ctx, size_t bytes, void **out) {
     return SVX_OK;
 }
 
+int svx_block_reserve(svx_ctx *ctx, void **block, size_t *block_bytes, size_t bytes, const char *what) {
+    if (bytes <= *block_bytes) return SVX_OK;
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // pending work may still use the old block
+    if (*block) SVX_HIP(ctx, hipFree(*block));
+    *block = nullptr;
+    *block_bytes = 0;
+    const size_t want = bytes + (bytes >> 2) + 4096;
+    hipError_t e = hipMalloc(block, want);
+    if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "%s: %zu bytes of device memory: %s", what, want, hipGetErrorString(e));
+    *block_bytes = want;
+    return SVX_OK;
+}
+
+int svx_pinned_mark_read(svx_ctx *ctx) {
+    if (!ctx->pinned_read) SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->pinned_read, hipEventDisableTiming));
+    SVX_HIP(ctx, hipEventRecord(ctx->pinned_read, ctx->stream));
+    ctx->pinned_busy = true;
+    return SVX_OK;
+}
+
 int svx_pinned_reserve(svx_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->pinned_busy) {                                    // an earlier call's copy out of the buffer may still be queued
+        SVX_HIP(ctx, hipEventSynchronize(ctx->pinned_read));
+        ctx->pinned_busy = false;
+    }
     if (bytes > ctx->pinned_bytes) {
         SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->pinned) SVX_HIP(ctx, hipHostFree(ctx->pinned));
@@ -37,6 +61,36 @@ int svx_pinned_reserve(svx_ctx *ctx, size_t bytes, void **out) {
         ctx->pinned_bytes = want;
     }
     *out = ctx->pinned;
+    return SVX_OK;
+}
+
+// Options: built-in default and the environment variable that overrides it when a context is created.
+static const struct { int builtin; const char *env; } svx_option_table[SVX_OPT_COUNT] = {
+    /* SVX_OPT_MATRIX_CORES */ {-1, "SVX_MX"},
+    /* SVX_OPT_LR_TWO_SWEEPS */ {0, "SVX_LR_TWO_SWEEPS"},
+    /* SVX_OPT_SWEEP_WAVES */ {3, "SVX_SWEEP_OCC"},
+    /* SVX_OPT_SWEEP_WAVES_BOTH */ {3, "SVX_SWEEP_OCC_BOTH"},
+    /* SVX_OPT_CENSUS97_PACKED */ {1, "SVX_CENSUS97_PACKED"},
+    /* SVX_OPT_MX_STRIP_ROWS */ {0, "SVX_MX_STRIP_ROWS"},
+    /* SVX_OPT_STAGE_TIMES */ {0, "SVX_STAGE_TIMES"},
+};
+
+int svx_option_default(int option) {
+    if (option < 0 || option >= SVX_OPT_COUNT) return 0;
+    const char *e = getenv(svx_option_table[option].env);
+    return e && e[0] ? atoi(e) : svx_option_table[option].builtin;
+}
+
+SVX_API int svx_set_option(svx_ctx *ctx, int option, int value) {
+    if (!ctx) return SVX_ERR_INVALID_ARG;
+    SVX_REQUIRE(ctx, option >= 0 && option < SVX_OPT_COUNT, SVX_ERR_INVALID_ARG, "svx_set_option: unknown option");
+    ctx->opt[option] = value;
+    return SVX_OK;
+}
+
+SVX_API int svx_get_option(const svx_ctx *ctx, int option, int *value) {
+    if (!value || option < 0 || option >= SVX_OPT_COUNT) return SVX_ERR_INVALID_ARG;
+    *value = svx_opt(ctx, option);
     return SVX_OK;
 }
 
@@ -78,6 +132,13 @@ SVX_API int svx_create(int device, svx_ctx **out) {
     c->pinned = nullptr;
     c->pinned_bytes = 0;
     c->err[0] = 0;
+    c->arena = nullptr;
+    c->arena_bytes = 0;
+    c->tri = nullptr;
+    c->tri_bytes = 0;
+    c->pinned_read = nullptr;
+    c->pinned_busy = false;
+    for (int o = 0; o < SVX_OPT_COUNT; ++o) c->opt[o] = svx_option_default(o);
     *out = c;
     return SVX_OK;
 }
@@ -87,13 +148,19 @@ SVX_API int svx_destroy(svx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->tri) (void)hipFree(ctx->tri);
+    if (ctx->pinned_read) (void)hipEventDestroy(ctx->pinned_read);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
     return SVX_OK;
 }
 
 SVX_API int svx_set_stream(svx_ctx *ctx, void *hip_stream) {
-    if (!ctx) return SVX_ERR_INVALID_ARG;
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    // The workspace is shared by every call of the context: work queued on the old stream must not overlap work on the new one.
+    if ((hipStream_t)hip_stream != ctx->stream) SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     return SVX_OK;
 }

@@ -490,6 +490,7 @@ __global__ __launch_bounds__(256) void lr_check_partial_kernel(float *__restrict
     if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
     float *dl = dl_all + ((long)blockIdx.z * rows + y) * cols;
     const float d1 = dl[x];
+    if (!(d1 >= 0.0f) || !(d1 < (float)cols)) { dl[x] = invalid; return; }       // no disparity (negative, NaN, beyond the row): reads nothing
     const int xr = x - (int)d1;
     if (xr < 2) { dl[x] = invalid; return; }
     const int n_chunks = (max_disp + 63) >> 6;
@@ -505,11 +506,11 @@ static int launch_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     const int n_strips = (rows - 4 + strip_rows - 1) / strip_rows;
     const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
     dim3 grid(svx_cdiv(n_xblocks, 2), n_strips, n_frames);
-    // Tuning knob: SVX_SWEEP_OCC=2 selects the build that may use up to 256 VGPRs (2 wavefronts per SIMD).
-    static const int occ = [] { const char *e = getenv("SVX_SWEEP_OCC"); return e ? atoi(e) : 3; }();
+    // SVX_OPT_SWEEP_WAVES = 2 selects the build that may use up to 256 VGPRs (2 wavefronts per SIMD).
+    const int occ = svx_opt(ctx, SVX_OPT_SWEEP_WAVES);
     if (partial) {
         if (MIRROR) return svx_fail(ctx, SVX_ERR_INVALID_ARG, "both-view sweep runs in the left view");
-        static const int occ_both = [] { const char *e = getenv("SVX_SWEEP_OCC_BOTH"); return e ? atoi(e) : 3; }();
+        const int occ_both = svx_opt(ctx, SVX_OPT_SWEEP_WAVES_BOTH);
         if (occ_both == 3)
             dense_wta5x5_sweep_kernel<3, WORDS, false, true><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, n_xblocks, disparity, write_border, partial);
         else
@@ -522,13 +523,9 @@ static int launch_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     return SVX_OK;
 }
 
-// SVX_MX in the environment: unset = matrix cores for the both-views search only, 0 = never, 1 = wherever they apply.
-static int svx_mx_mode() {
-    static const int mode = [] { const char *e = getenv("SVX_MX"); return e ? atoi(e) : -1; }();
-    return mode;
-}
-static bool both_views_on_matrix_cores(int rows, int cols, int words, int max_disp) {
-    return svx_mx_mode() != 0 && words == 2 && svx_mx_sweep_eligible(rows, cols, max_disp);
+// SVX_OPT_MATRIX_CORES: -1 = matrix cores for the both-views search only, 0 = never, 1 = wherever they apply.
+static bool both_views_on_matrix_cores(const svx_ctx *ctx, int rows, int cols, int words, int max_disp) {
+    return svx_opt(ctx, SVX_OPT_MATRIX_CORES) != 0 && words == 2 && svx_mx_sweep_eligible(rows, cols, max_disp);
 }
 
 // words: 32-bit words per census descriptor (1 or 2); mirror: search in the other view (see sweep_chunk).
@@ -541,8 +538,8 @@ static int launch_dense(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
         SVX_LAUNCH_CHECK(ctx, "dense_wta5x5_plain_kernel");
         return SVX_OK;
     }
-    // Tuning knob: SVX_MX=1 also runs the single-view search on the matrix cores (measured 3 % slower than the sweep).
-    if (svx_mx_mode() == 1 && words == 2 && !mirror && svx_mx_sweep_eligible(rows, cols, max_disp))
+    // SVX_OPT_MATRIX_CORES = 1 also runs the single-view search on the matrix cores (measured 3 % slower than the sweep).
+    if (svx_opt(ctx, SVX_OPT_MATRIX_CORES) == 1 && words == 2 && !mirror && svx_mx_sweep_eligible(rows, cols, max_disp))
         return svx_launch_mx_sweep(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border, nullptr);
     if (words == 1) return mirror ? launch_sweep<1, true>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border)
                                   : launch_sweep<1, false>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, write_border);
@@ -837,8 +834,8 @@ SVX_API int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census,
     const bool fast = (((uintptr_t)img & 3u) == 0) && (((uintptr_t)census & 15u) == 0);
     const long total_bytes = (long)rows * cols * n_frames;
     const dim3 tgrid(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97T_H), n_frames);
-    // Tuning knob: SVX_CENSUS97_PACKED=0 selects the one-comparison-per-instruction form of the tile kernel.
-    static const int packed = [] { const char *e = getenv("SVX_CENSUS97_PACKED"); return e ? atoi(e) : 1; }();
+    // SVX_OPT_CENSUS97_PACKED = 0 selects the one-comparison-per-instruction form of the tile kernel.
+    const int packed = svx_opt(ctx, SVX_OPT_CENSUS97_PACKED);
     if (fast && cols % 4 == 0) {
         if (packed) census9x7_tile_kernel<true, true><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
         else census9x7_tile_kernel<true, false><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
@@ -857,7 +854,7 @@ SVX_API int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census,
 // svx_census9x7_u8 of both images of a batch of pairs, in one launch where the tile kernel applies.
 static int census9x7_pair(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, uint32_t *cl, uint32_t *cr, int rows, int cols, int n_frames) {
     const bool fast = (((uintptr_t)left & 3u) == 0) && (((uintptr_t)right & 3u) == 0) && (((uintptr_t)cl & 15u) == 0) && (((uintptr_t)cr & 15u) == 0);
-    static const int packed = [] { const char *e = getenv("SVX_CENSUS97_PACKED"); return e ? atoi(e) : 1; }();
+    const int packed = svx_opt(ctx, SVX_OPT_CENSUS97_PACKED);
     if (!fast || !packed || cols < 9 || 2 * n_frames > 65535 || svx_cdiv(rows, C97T_H) > 65535) {
         const int rc = svx_census9x7_u8(ctx, left, cl, rows, cols, n_frames);
         return rc ? rc : svx_census9x7_u8(ctx, right, cr, rows, cols, n_frames);
@@ -891,6 +888,8 @@ __global__ __launch_bounds__(256) void lr_check_kernel(float *__restrict__ dl_al
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
     const float d1 = dl[(long)y * cols + x];
+    // a value that is no disparity (negative, such as an earlier pass's invalid marker, NaN, beyond the row) is invalid and reads nothing
+    if (!(d1 >= 0.0f) || !(d1 < (float)cols)) { dl[(long)y * cols + x] = invalid; return; }
     const int xr = x - (int)d1;
     // a match whose right pixel falls outside the searched region of the right view cannot be confirmed
     if (xr < 2 || fabsf(dr[(long)y * cols + xr] - d1) > threshold) dl[(long)y * cols + x] = invalid;
@@ -919,8 +918,9 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const uint32_t *__restric
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
     const float f = disp[(long)y * cols + x];
+    if (!(f >= 1.0f) || !(f < (float)max_disp)) return;                           // also NaN and values no int can hold
     const int d = (int)f;
-    if (!(f >= 1.0f) || (float)d != f || d + 1 > max_disp - 1 || x - (d + 1) < 5) return;
+    if ((float)d != f || d + 1 > max_disp - 1 || x - (d + 1) < 5) return;
     int c0 = 0, c1 = 0, c2 = 0;
 #pragma unroll
     for (int m = -2; m <= 2; ++m) {
@@ -997,7 +997,7 @@ static int launch_both_views(svx_ctx *ctx, const uint32_t *cl, const uint32_t *c
     // Two-word descriptors at up to 256 disparities: the cost values are formed on the matrix cores (at 128: 1.37 ms against
     // 1.57 ms per 64 KITTI frames, and a cheaper merge); SVX_MX=0 keeps the vector sweep.  The partial keys take half
     // the room of the vector sweep's partial minima, so the buffer sized for those is large enough.
-    const bool mx = both_views_on_matrix_cores(rows, cols, words, max_disp);
+    const bool mx = both_views_on_matrix_cores(ctx, rows, cols, words, max_disp);
     for (int f0 = 0; f0 < n_frames; f0 += group) {
         const int nf = n_frames - f0 < group ? n_frames - f0 : group;
         const uint32_t *gl = cl + (size_t)f0 * n * words, *gr = cr + (size_t)f0 * n * words;
@@ -1066,13 +1066,13 @@ SVX_API int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left
 }
 
 // Which kernel the dense search of this size runs: 0 = vector sweep, 1 = matrix-core search, 2 = one thread per pixel.
-SVX_API int svx_dense_kernel_choice(int rows, int cols, int words, int max_disp, int both_views) {
+SVX_API int svx_dense_kernel_choice(const svx_ctx *ctx, int rows, int cols, int words, int max_disp, int both_views) {
     if (both_views) {
         if (!both_views_eligible(rows, cols, max_disp) || rows > 65535) return 2;
-        return both_views_on_matrix_cores(rows, cols, words, max_disp) ? 1 : 0;
+        return both_views_on_matrix_cores(ctx, rows, cols, words, max_disp) ? 1 : 0;
     }
     if (max_disp > SW_DMASK + 1 || cols < SW_T + 4 || rows < 5) return 2;
-    return svx_mx_mode() == 1 && words == 2 && svx_mx_sweep_eligible(rows, cols, max_disp) ? 1 : 0;
+    return svx_opt(ctx, SVX_OPT_MATRIX_CORES) == 1 && words == 2 && svx_mx_sweep_eligible(rows, cols, max_disp) ? 1 : 0;
 }
 
 static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
@@ -1083,8 +1083,8 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     if (rc) return rc;
     const size_t n = (size_t)rows * cols * n_frames;
     const bool lr = lr_threshold >= 0.f;
-    // Tuning knob: SVX_LR_TWO_SWEEPS=1 computes the right view with a second (mirrored) sweep instead of from the first one's cost values.
-    static const bool two_sweeps = [] { const char *e = getenv("SVX_LR_TWO_SWEEPS"); return e && e[0] == '1'; }();
+    // SVX_OPT_LR_TWO_SWEEPS = 1 computes the right view with a second (mirrored) sweep instead of from the first one's cost values.
+    const bool two_sweeps = svx_opt(ctx, SVX_OPT_LR_TWO_SWEEPS) == 1;
     // the partial minima of the one-sweep path take 80 words per (row, x-block, 64-disparity chunk) and frame
     const int group = lr && !two_sweeps ? both_views_group_frames(rows, cols, n_frames, max_disp) : 0;
     const bool both = group > 0;

@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl
     if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
     float *dl = dl_all + ((long)blockIdx.z * rows + y) * cols;
     const float d1 = dl[x];
+    if (!(d1 >= 0.0f) || !(d1 < (float)cols)) { dl[x] = invalid; return; }       // no disparity (negative, NaN, beyond the row): reads nothing
     const int xr = x - (int)d1;
     if (xr < 2) { dl[x] = invalid; return; }
     const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * 32 * T);
@@ -561,8 +562,8 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
         const long cost = rounds * ((out_rows + k - 1) / k + 4 + 2);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; n_strips = k; }
     }
-    // Tuning knob: SVX_MX_STRIP_ROWS forces the output rows per strip.
-    static const int forced_rows = [] { const char *e = getenv("SVX_MX_STRIP_ROWS"); return e ? atoi(e) : 0; }();
+    // SVX_OPT_MX_STRIP_ROWS > 0 forces the output rows per strip.
+    const int forced_rows = svx_opt(ctx, SVX_OPT_MX_STRIP_ROWS);
     const int strip_rows = forced_rows > 0 ? forced_rows : (out_rows + n_strips - 1) / n_strips;
     n_strips = (out_rows + strip_rows - 1) / strip_rows;
     dim3 grid(mx_xblocks(cols), n_strips, n_frames);
@@ -596,7 +597,7 @@ int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, 
     return SVX_OK;
 }
 
-// The matrix-core form of svx_dense_wta_both on two-word descriptors (max_disp <= 128, cols >= 36, rows >= 5), run
+// The matrix-core form of svx_dense_wta_both on two-word descriptors (max_disp <= 256, cols >= 36, rows >= 5), run
 // whatever the library's default choice of kernel is: left map, and with disp_right != NULL the right map from the
 // same accumulators.  Same results as svx_dense_wta / svx_dense_wta_both.
 SVX_API int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,

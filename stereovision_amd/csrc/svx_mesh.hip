@@ -408,18 +408,16 @@ int prior_from_triangles(svx_ctx *ctx, const char *what, const int32_t *pts_xy_h
             h[6 * i + 2 * k] = pts_xy_host[2 * tris[i].v[k]];
             h[6 * i + 2 * k + 1] = pts_xy_host[2 * tris[i].v[k] + 1];
         }
-    void *dbuf = nullptr;
+    // triangle corners and planes live in a block of the context that is kept between calls
     const size_t xy_bytes = (size_t)nt * 6 * sizeof(int32_t), abc_bytes = (size_t)nt * 3 * sizeof(float);
-    hipError_t e = hipMalloc(&dbuf, xy_bytes + abc_bytes);
-    if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "%s: triangle buffer: %s", what, hipGetErrorString(e));
-    int32_t *d_xy = (int32_t *)dbuf;
-    float *d_abc = (float *)((char *)dbuf + xy_bytes);
-    rc = SVX_OK;
-    if (hipMemcpyAsync(d_xy, h, xy_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = svx_fail(ctx, SVX_ERR_HIP, "%s: upload failed", what);
+    rc = svx_block_reserve(ctx, &ctx->tri, &ctx->tri_bytes, xy_bytes + abc_bytes, what);
+    if (rc) return rc;
+    int32_t *d_xy = (int32_t *)ctx->tri;
+    float *d_abc = (float *)((char *)ctx->tri + xy_bytes);
+    if (hipMemcpyAsync(d_xy, h, xy_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return svx_fail(ctx, SVX_ERR_HIP, "%s: upload failed", what);
+    rc = svx_pinned_mark_read(ctx);
     if (!rc) rc = svx_plane_fit(ctx, d_xy, nt, disparities, rows, cols, d_abc);
     if (!rc) rc = svx_plane_prior_raster(ctx, d_xy, d_abc, nt, rows, cols, prior);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dbuf);
     return rc;
 }
 

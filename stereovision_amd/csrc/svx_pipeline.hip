@@ -37,25 +37,22 @@ struct Arena {
     }
 };
 
-// Stage clock: the pipeline is host-synchronous at its list hand-overs anyway; a mark waits for the stream and books
-// the time since the previous mark to one stage.
+// Stage clock, active only under SVX_OPT_STAGE_TIMES: a mark waits for the stream and books the time since the
+// previous mark to one stage.  Without the option a mark does nothing and the stage times read 0.
 struct StageClock {
     svx_ctx *ctx;
+    bool on;
     std::chrono::steady_clock::time_point t;
-    explicit StageClock(svx_ctx *c) : ctx(c), t(std::chrono::steady_clock::now()) {
+    explicit StageClock(svx_ctx *c) : ctx(c), on(svx_opt(c, SVX_OPT_STAGE_TIMES) != 0), t(std::chrono::steady_clock::now()) {
         for (int i = 0; i < SVX_PIPELINE_STAGES; ++i) c->stage_ms[i] = 0.0;
     }
     void mark(int stage) {
+        if (!on) return;
         (void)hipStreamSynchronize(ctx->stream);
         const auto now = std::chrono::steady_clock::now();
         ctx->stage_ms[stage] += std::chrono::duration<double, std::milli>(now - t).count();
         t = now;
     }
-};
-
-struct ArenaGuard {
-    void *p = nullptr;
-    ~ArenaGuard() { if (p) (void)hipFree(p); }
 };
 
 }  // namespace
@@ -88,7 +85,8 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         cells_needed = std::min(cells_needed, max_cells);
     }
 
-    // one device allocation for every intermediate image and list; laid out twice (measure, then place)
+    // one device block for every intermediate image and list, kept in the context between calls and grown on demand;
+    // laid out twice (measure, then place)
     uint8_t *L, *Rr, *La, *Ra, *grad;
     uint32_t *cL, *cR;
     int32_t *pts, *kpl, *kpr, *conf_x, *conf_y, *inv_x, *inv_y, *rs_xy, *stage_xy;
@@ -113,9 +111,15 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     layout(measure);
     Arena a;
     a.cap = measure.used + 256;
-    ArenaGuard guard;
-    if (hipMalloc(&guard.p, a.cap) != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: %zu bytes of device memory", a.cap);
-    a.base = (char *)guard.p;
+    if (a.cap > ctx->arena_bytes) {
+        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->arena) SVX_HIP(ctx, hipFree(ctx->arena));
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+        if (hipMalloc(&ctx->arena, a.cap) != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: %zu bytes of device memory", a.cap);
+        ctx->arena_bytes = a.cap;
+    }
+    a.base = (char *)ctx->arena;
     layout(a);
 
     StageClock clk(ctx);

@@ -47,22 +47,26 @@ def gather_to_rank0(disp):
 
 
 def gather_point_clouds_to_rank0(xyz):
-    """Gathers every rank's [n_r, 3] point tensor (n_r differs per rank) to rank 0: first the counts
-    (one all_gather of an int64 per rank), then the payloads, each rank's padded to the largest count so
-    that one fixed-size gather moves them.  Returns (list of [n_r, 3] tensors indexed by rank, counts) on
-    rank 0 and (None, counts) elsewhere."""
+    """Gathers every rank's [n_r, 3] point tensor (n_r differs per rank) to rank 0: first the counts (one all_gather of
+    an int64 per rank), then one grouped batch of point-to-point transfers in which every peer with points sends exactly
+    its n_r points and rank 0 receives each into a buffer of that size (no padding to the largest cloud: over xGMI every
+    peer has its own link to GPU 0, so the transfers run side by side).  Returns (list of [n_r, 3] tensors indexed by
+    rank, counts) on rank 0 and (None, counts) elsewhere."""
     if world_size() == 1:
         return [xyz], [int(xyz.shape[0])]
     rank, world = dist.get_rank(), world_size()
+    xyz = xyz.contiguous()
     n = torch.tensor([xyz.shape[0]], dtype=torch.int64, device=xyz.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
-    m = max(max(counts), 1)
-    padded = torch.zeros((m, 3), dtype=xyz.dtype, device=xyz.device)
-    padded[:xyz.shape[0]] = xyz
-    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
-    dist.gather(padded, bufs, dst=0)
-    if rank != 0:
-        return None, counts
-    return [bufs[r][:counts[r]] for r in range(world)], counts
+    if rank == 0:
+        bufs = [xyz] + [torch.empty((counts[r], 3), dtype=xyz.dtype, device=xyz.device) for r in range(1, world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(1, world) if counts[r] > 0]
+    else:
+        bufs = None
+        ops = [dist.P2POp(dist.isend, xyz, 0)] if counts[rank] > 0 else []
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return bufs, counts

@@ -6,7 +6,7 @@ import numpy as np
 
 import oracle_lib as O
 
-SIZES = [(32, 64, 16), (64, 128, 32), (368, 1232, 128)]          # rows, cols, disparities
+SIZES = [(32, 64, 16), (64, 128, 32), (480, 640, 64), (368, 1232, 128)]          # rows, cols, disparities (480x640/64 = configs[0])
 
 
 def inputs(rows, cols, D):

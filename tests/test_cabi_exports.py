@@ -45,10 +45,22 @@ def test_dense_kernel_choice_is_a_host_side_query():
     if os.environ.get("SVX_MX") is not None:
         return                                              # the tuning knob overrides the defaults checked here
     lib = S.load_library()
-    assert lib.svx_dense_kernel_choice(368, 1232, 2, 128, 1) == 1      # both views, two-word descriptors: matrix cores
-    assert lib.svx_dense_kernel_choice(1072, 1920, 2, 256, 1) == 1
-    assert lib.svx_dense_kernel_choice(2160, 3840, 2, 512, 1) == 0     # more than 256 disparities: vector sweep
-    assert lib.svx_dense_kernel_choice(368, 1232, 1, 128, 1) == 0      # one-word descriptors
-    assert lib.svx_dense_kernel_choice(368, 1232, 2, 128, 0) == 0      # single view
-    assert lib.svx_dense_kernel_choice(4, 1232, 2, 128, 0) == 2
+    assert lib.svx_dense_kernel_choice(None, 368, 1232, 2, 128, 1) == 1      # both views, two-word descriptors: matrix cores
+    assert lib.svx_dense_kernel_choice(None, 1072, 1920, 2, 256, 1) == 1
+    assert lib.svx_dense_kernel_choice(None, 2160, 3840, 2, 512, 1) == 0     # more than 256 disparities: vector sweep
+    assert lib.svx_dense_kernel_choice(None, 368, 1232, 1, 128, 1) == 0      # one-word descriptors
+    assert lib.svx_dense_kernel_choice(None, 368, 1232, 2, 128, 0) == 0      # single view
+    assert lib.svx_dense_kernel_choice(None, 4, 1232, 2, 128, 0) == 2
     assert S.dense_kernel_name(368, 1232, 2, 128, True) == "dense_wta_mx_kernel"
+
+
+def test_options_default_from_the_environment_only_at_creation():
+    """svx_get_option(NULL, ...) is what a new context would start from: the built-in value unless its variable is set."""
+    lib = S.load_library()
+    v = C.c_int(99)
+    if os.environ.get("SVX_SWEEP_OCC") is None:
+        assert lib.svx_get_option(None, S.OPT_SWEEP_WAVES, C.byref(v)) == 0 and v.value == 3
+    if os.environ.get("SVX_STAGE_TIMES") is None:
+        assert lib.svx_get_option(None, S.OPT_STAGE_TIMES, C.byref(v)) == 0 and v.value == 0
+    assert lib.svx_get_option(None, 1000, C.byref(v)) == -1
+    assert lib.svx_set_option(None, S.OPT_SWEEP_WAVES, 2) == -1        # options belong to a context

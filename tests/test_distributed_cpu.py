@@ -1,4 +1,4 @@
-"""Multi-process (gloo, world_size 2, CPU) test of the frame-sharding logic bench.py uses on N GPUs:
+"""Multi-process (gloo, world_size 2 and 4, CPU) test of the frame-sharding logic bench.py uses on N GPUs:
 every rank owns its own batch (weak scaling), the timed region is bracketed by barriers, the step time
 is the MAX over ranks, the throughput is the units of all ranks over that time, and the evaluation
 gather brings every rank's disparity maps to rank 0.  The compute itself is replaced by the CPU oracle
@@ -54,7 +54,8 @@ def _worker(rank, world, port, out_dir):
     else:
         assert gathered is None
     # variable-length point clouds (one per rank, different sizes, an empty one included) gathered to rank 0
-    n_mine = [0, 37][rank] if world == 2 else 11 * rank
+    sizes = [0, 37] if world == 2 else [5, 0, 61, 23]
+    n_mine = sizes[rank]
     Q = np.array([[1, 0, 0, -30.0], [0, 1, 0, -12.0], [0, 0, 0, 700.0], [0, 0, 1.0 / 0.5, 0]], np.float64)
     ys, xs = np.nonzero(disp[0] > 0)
     pts = np.stack([xs, ys], 1).astype(np.int32)[:n_mine]
@@ -66,7 +67,7 @@ def _worker(rank, world, port, out_dir):
             l2, r2 = synth.stereo_batch(rows, cols, D, 1, seed0=r * frames_per_rank)
             d2 = O.dense_wta5x5(O.census5x5(O.u8_to_s8(l2[0])), O.census5x5(O.u8_to_s8(r2[0])), D)
             y2, x2 = np.nonzero(d2 > 0)
-            want, _ = O.point_cloud(np.stack([x2, y2], 1).astype(np.int32)[:[0, 37][r]], d2, Q)
+            want, _ = O.point_cloud(np.stack([x2, y2], 1).astype(np.int32)[:sizes[r]], d2, Q)
             assert clouds[r].shape == (counts[r], 3) and np.array_equal(clouds[r].numpy(), want)
         open(os.path.join(out_dir, "ok"), "w").write("ok")
     else:
@@ -75,7 +76,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_gather(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharding_and_gathers(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / "ok").exists()

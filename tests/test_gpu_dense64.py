@@ -123,6 +123,56 @@ def test_lr_check(ctx, rows, cols, threshold):
         assert np.array_equal(got[f], O.lr_check(dl[f], dr[f], threshold, -7.0))
 
 
+def test_lr_check_values_that_are_no_disparity(ctx):
+    """Left maps holding an earlier pass's invalid markers, NaN or huge values: such pixels become invalid and nothing is
+    read for them (a negative value used to address the next row, a huge one memory past the frame)."""
+    rng = np.random.default_rng(11)
+    rows, cols = 24, 70
+    dl = rng.integers(0, 20, size=(3, rows, cols)).astype(np.float32)
+    dr = rng.integers(0, 20, size=(3, rows, cols)).astype(np.float32)
+    bad = np.array([-1.0, -10.0, np.nan, 1e9, -0.5, np.inf, -np.inf, float(cols), float(cols) - 1.0, 3e38], np.float32)
+    idx = rng.integers(0, dl.size, size=400)
+    dl.reshape(-1)[idx] = bad[rng.integers(0, len(bad), size=400)]
+    dl[2, -3:, -6:] = 1e9                       # the last pixels of the last frame
+    dl[2, -3:, :4] = -10.0
+    got = ctx.lr_check(dev(dl), dev(dr), 1.0, invalid=-7.0).cpu().numpy()
+    for f in range(3):
+        want = O.lr_check(dl[f], dr[f], 1.0, -7.0)
+        assert np.array_equal(got[f], want, equal_nan=True)
+        inner = got[f][2:-2, 2:-2]
+        src = dl[f][2:-2, 2:-2]
+        assert np.all(inner[~((src >= 0) & (src < cols))] == -7.0)
+
+
+@pytest.mark.parametrize("rows,cols,D,frames", [(375, 1242, 64, 2), (368, 1232, 128, 2), (1072, 1920, 200, 1), (540, 960, 256, 1),
+                                                 (300, 2000, 33, 1), (300, 2000, 65, 1), (300, 2000, 129, 1)])
+def test_matrix_search_equals_vector_sweep_on_whole_frames(ctx, rows, cols, D, frames):
+    """Every tile count of the matrix-core search (3, 5 and 9 tiles: up to 64, 128 and 256 disparities), both views, on
+    whole large frames against the vector sweep (itself checked against the oracle on bands of such frames): a build of
+    the matrix-core kernel that spills, or whose hand-placed instructions no longer fit the compiler's, shows up here."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    ls, rs = synth.stereo_batch(rows, cols, D, frames, seed0=7 + D)
+    cl, cr = ctx.census9x7(dev(ls)), ctx.census9x7(dev(rs))
+    ctx.set_option(S.OPT_MATRIX_CORES, 0)
+    try:
+        wl = ctx.dense_wta(cl, cr, D, S.VIEW_LEFT, 2)
+        wr = ctx.dense_wta(cl, cr, D, S.VIEW_RIGHT, 2)
+    finally:
+        ctx.set_option(S.OPT_MATRIX_CORES, -1)
+    ml, mr = ctx.dense_wta_matrix(cl, cr, D)
+    ml0, _ = ctx.dense_wta_matrix(cl, cr, D, both=False)
+    assert torch.equal(ml, wl), (ml != wl).nonzero()[:5].tolist()
+    assert torch.equal(ml0, wl), (ml0 != wl).nonzero()[:5].tolist()
+    assert torch.equal(mr, wr), (mr != wr).nonzero()[:5].tolist()
+    # a band of rows against the oracle, so that the two device kernels cannot be wrong together
+    hl, hr = cl.cpu().numpy().view(np.uint32), cr.cpu().numpy().view(np.uint32)
+    y0 = rows // 2
+    for view, got in ((0, ml), (1, mr)):
+        want = O.dense_wta_words(hl[0], hr[0], D, view, y0, y0 + 2)
+        assert np.array_equal(got[0].cpu().numpy()[y0:y0 + 2], want[y0:y0 + 2])
+
+
 @pytest.mark.parametrize("rows,cols,max_disp,thr", [(64, 200, 48, 1.0), (375, 1242, 128, 1.0), (40, 90, 16, -1.0), (368, 1232, 128, 0.0)])
 def test_fused_census9x7_lr(ctx, rows, cols, max_disp, thr):
     from stereovision_amd import synth

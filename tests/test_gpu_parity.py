@@ -158,6 +158,22 @@ def test_dense_wta_golden_and_batch(ctx):
         assert np.array_equal(got[f], want)
 
 
+def test_dense_census_wta_640x480_64_disparities(ctx):
+    """The reference's own CPU-runnable case (denseCensusStereo.cpp:257-266 on one 640x480 pair, 64 disparities): the
+    fused entry point against the oracle on the whole frame, the composed entry points too."""
+    from stereovision_amd import synth
+    rows, cols, D = 480, 640, 64
+    left, right, field = synth.stereo_pair(rows, cols, D, seed=0)
+    cl = O.census5x5(O.u8_to_s8(left)); cr = O.census5x5(O.u8_to_s8(right))
+    want = O.dense_wta5x5(cl, cr, D)
+    fused = ctx.dense_census_wta(dev(left), dev(right), D).cpu().numpy()
+    assert np.array_equal(fused, want), np.argwhere(fused != want)[:5]
+    got = ctx.dense_wta5x5(dev_u32(cl), dev_u32(cr), D).cpu().numpy()
+    assert np.array_equal(got, want)
+    inner = (slice(8, rows - 8), slice(D + 8, cols - 8))
+    assert float(np.mean(fused[inner] == field[inner])) > 0.97
+
+
 def test_dense_wta_recovers_generating_field(ctx):
     """Size-independent sanity property at the benchmark size: the WTA disparity equals the field the
     pair was generated with at almost every pixel (the reference reaches 0.992-0.994 on such data)."""

@@ -136,3 +136,19 @@ def test_lr_check_hand_example():
     assert out1[2, 8] == 3 and out1[2, 9] == 4 and out1[2, 3] == -1
     out0 = O.lr_check(dl, dr, 0.0)
     assert out0[2, 9] == -1 and out0[0, 0] == 0
+
+
+def test_lr_check_treats_what_is_no_disparity_as_invalid():
+    """Negative values (an earlier pass's markers), NaN, infinities and values beyond the row are invalidated without a read;
+    a second pass over a checked map therefore leaves it as it is."""
+    rows, cols = 7, 20
+    dl = np.full((rows, cols), 2.0, np.float32); dr = np.full((rows, cols), 2.0, np.float32)
+    for x, v in zip(range(4, 12), [-1.0, -10.0, np.nan, 1e9, np.inf, -np.inf, float(cols), -0.5]):
+        dl[3, x] = v
+    out = O.lr_check(dl, dr, 1.0, -1.0)
+    assert np.all(out[3, 4:12] == -1.0)
+    assert out[3, 12] == 2.0 and out[3, 3] == -1.0          # x_r = 1 < 2 cannot be confirmed
+    assert np.array_equal(O.lr_check(out, dr, 1.0, -1.0), out)
+    d = np.array([[1.0, np.nan, 1e9, -3.0]], np.float32).repeat(6, 0).repeat(4, 1)
+    c = np.zeros((6, 16, 2), np.uint32)
+    assert np.array_equal(O.subpixel_refine(c, c, 8, d), d, equal_nan=True)

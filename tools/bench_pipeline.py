@@ -32,7 +32,11 @@ def main():
             n_pts += len(ctx.high_perf_stereo(l, r, p, out))
         torch.cuda.synchronize()
         gpu_ms = (time.perf_counter() - t0) * 1e3 / len(dev)
+        ctx.set_option(S.OPT_STAGE_TIMES, 1)                        # one more frame with a synchronisation at every stage mark
+        out.zero_()
+        ctx.high_perf_stereo(dev[-1][0], dev[-1][1], p, out)
         stages = ctx.pipeline_stage_times()
+        ctx.set_option(S.OPT_STAGE_TIMES, 0)
         rec = {"pipeline": "svx_high_perf_stereo", "rows": rows, "cols": cols, "nIters": n_iters, "ms_per_frame": round(gpu_ms, 2),
                "frames_per_s": round(1e3 / gpu_ms, 1), "points_per_frame": n_pts // len(dev), "stage_ms_last_frame": stages}
         if "--cpu" in sys.argv:
