@@ -155,6 +155,16 @@ int svx_dense_wta5x5(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *
 int svx_dense_census_wta_u8(svx_ctx *ctx, const uint8_t *left, const uint8_t *right,
                             int rows, int cols, int n_frames, int max_disp, float *disparity);
 
+/* svx_dense_census_wta_u8 without any allocation.  No counterpart in the reference: it is for callers that cannot
+ * call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it).  Same arguments and
+ * results; the two census batches live in a fixed 32 MiB array of the library's code object (one copy per device,
+ * held until the process ends) instead of the context's workspace, so n_frames*rows*cols is limited to
+ * SVX_NOALLOC_MAX_PIXELS (SVX_ERR_UNSUPPORTED beyond it).  It calls no hipMalloc/hipFree.  All calls on one device share
+ * that array: calls that overlap on one device (two contexts or streams) race. */
+#define SVX_NOALLOC_MAX_PIXELS 4194304
+int svx_dense_census_wta_u8_noalloc(svx_ctx *ctx, const uint8_t *left, const uint8_t *right,
+                                    int rows, int cols, int n_frames, int max_disp, float *disparity);
+
 /* ---- a9: batched full-range epipolar search ------------------------------
  * Replaces epipolarMatching, highPerfStereo/highPerfStereoLib.h:211-214,
  * highPerfStereoLib.cpp:88-139, for n points at once.  out_cost is the

@@ -38,6 +38,7 @@ EXPORTS = {
                               _vp, _vp, _vp, C.POINTER(_i)]),
     "svx_dense_wta5x5": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svx_dense_census_wta_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "svx_dense_census_wta_u8_noalloc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svx_epipolar_match_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "svx_census_nxn_words": (_i, [_i]),
     "svx_census_nxn_s8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -323,6 +324,16 @@ class Context:
             out = t.empty(left.shape, dtype=t.float32, device=left.device)
         _check_dev(out, t.float32, "out")
         self._call("svx_dense_census_wta_u8", _dptr(left), _dptr(right), r, c, f, int(max_disp), _dptr(out))
+        return out
+
+    def dense_census_wta_noalloc(self, left, right, max_disp, out):
+        """svx_dense_census_wta_u8_noalloc: the caller passes every buffer, the library allocates nothing."""
+        t = self._torch
+        _check_dev(left, t.uint8, "left"); _check_dev(right, t.uint8, "right"); _check_dev(out, t.float32, "out")
+        if left.shape != right.shape or out.shape != left.shape:
+            raise SvxError(-2, "Mismatching image sizes")
+        f, r, c = _frames(left)
+        self._call("svx_dense_census_wta_u8_noalloc", _dptr(left), _dptr(right), r, c, f, int(max_disp), _dptr(out))
         return out
 
     # ---- 64-bit descriptors, right view, left-right check ----

@@ -21,6 +21,7 @@ struct svx_ctx {
     size_t arena_bytes;
     void *tri;                              // triangle corners and planes of the mesh prior, kept between calls
     size_t tri_bytes;
+    void *static_scratch;                   // this device's address of the code object's fixed scratch array (svx_dense.hip)
     hipEvent_t pinned_read;                 // recorded behind the last asynchronous copy out of `pinned`
     bool pinned_busy;
 };
@@ -69,6 +70,7 @@ int svx_pinned_mark_read(svx_ctx *ctx);
 // Grows a device block kept in the context (pointer and size fields passed in) to at least `bytes`.
 int svx_block_reserve(svx_ctx *ctx, void **block, size_t *block_bytes, size_t bytes, const char *what);
 int svx_enter(svx_ctx *ctx);
+int svx_static_scratch_locate(svx_ctx *ctx);   // svx_dense.hip: finds this device's copy of the fixed scratch array
 
 // Matrix-core form of the dense search on two-word descriptors (svx_dense_mx.hip).
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp);

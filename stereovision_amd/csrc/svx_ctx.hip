@@ -139,6 +139,9 @@ SVX_API int svx_create(int device, svx_ctx **out) {
     c->pinned_read = nullptr;
     c->pinned_busy = false;
     for (int o = 0; o < SVX_OPT_COUNT; ++o) c->opt[o] = svx_option_default(o);
+    c->static_scratch = nullptr;
+    (void)svx_static_scratch_locate(c);     // on failure the pointer stays null and only the allocation-free entry point refuses to run
+    c->err[0] = 0;
     *out = c;
     return SVX_OK;
 }

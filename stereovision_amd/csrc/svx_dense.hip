@@ -575,6 +575,43 @@ SVX_API int svx_dense_census_wta_u8(svx_ctx *ctx, const uint8_t *left, const uin
 }
 
 // ---------------------------------------------------------------------------
+// svx_dense_census_wta_u8 for callers that cannot allocate (code under graph capture, serving loops): the two census
+// batches, which the other entry point keeps in the context's workspace, live in a fixed array of the code object.
+// Every device the library runs on holds its own copy of the array at its own address, found once per context (with
+// the context's device current) and used as `ctx->static_scratch` from then on: in host code the array's NAME is a
+// host-side stand-in, not a device address.
+static __device__ __align__(256) unsigned char svx_static_scratch[(size_t)SVX_NOALLOC_MAX_PIXELS * 2 * sizeof(uint32_t)];
+
+// Called by svx_create with the new context's device current.
+int svx_static_scratch_locate(svx_ctx *ctx) {
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(svx_static_scratch));
+    if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_HIP, "hipGetSymbolAddress(svx_static_scratch) failed: %s", hipGetErrorString(e));
+    ctx->static_scratch = p;
+    return SVX_OK;
+}
+
+SVX_API int svx_dense_census_wta_u8_noalloc(svx_ctx *ctx, const uint8_t *left, const uint8_t *right,
+                                            int rows, int cols, int n_frames, int max_disp, float *disparity) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    rc = dense_args_ok(ctx, left, right, disparity, rows, cols, n_frames, max_disp);
+    if (rc) return rc;
+    const size_t n = (size_t)rows * cols * n_frames;
+    if (n > (size_t)SVX_NOALLOC_MAX_PIXELS)
+        return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "svx_dense_census_wta_u8_noalloc: %zu pixels per call, the fixed scratch holds %d",
+                        n, SVX_NOALLOC_MAX_PIXELS);
+    SVX_REQUIRE(ctx, ctx->static_scratch != nullptr, SVX_ERR_HIP, "svx_dense_census_wta_u8_noalloc: the fixed scratch was not found on this device");
+    // every pixel of both census batches is written before the search reads it (SVX_CENSUS_ZERO_REST): nothing to clear
+    uint32_t *cl = (uint32_t *)ctx->static_scratch, *cr = cl + n;
+    rc = svx_census5x5_u8(ctx, left, cl, rows, cols, n_frames, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST);
+    if (rc) return rc;
+    rc = svx_census5x5_u8(ctx, right, cr, rows, cols, n_frames, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST);
+    if (rc) return rc;
+    return launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1);
+}
+
+// ---------------------------------------------------------------------------
 // 64-bit descriptors: 9x7 census, dense search in either view, left-right check.
 // The reference has no 9x7 census and no dense left-right check; these generalise its 5x5 dense
 // matcher (denseCensusStereo.cpp:87-131) along the lines of its generic NxN census
