@@ -29,27 +29,32 @@ typedef float mx_v16f __attribute__((ext_vector_type(16)));
 #define MX_PLANE_PAD 0      // measurement aid: extra pixels between the two planes of a staged row
 #endif
 #ifndef MX_P
-#define MX_P 4      // right operands fetched this many matrix instructions ahead
-#endif
+#define MX_P 5      // right operands fetched this many matrix instructions ahead; divides the instructions of a row (5 or 10 per tile), so a
+#endif              // row's instruction s always finds its operand in slot s % MX_P, also when the previous row fetched it
 constexpr int MX_M = 32;                 // left columns per wavefront
 #ifndef MX_MAX_DISP
 #define MX_MAX_DISP 256   // 3, 5 or 9 tiles of 32 right columns (17 tiles for 512 disparities spill: 27.5 against 13.3 ms at 4K)
 #endif
 
+constexpr int MX_W = 4;                  // wavefronts (x-blocks of 32 left columns) per workgroup: they share one staged image of the census rows
+constexpr int MX_NBUF = 3;               // staged rows in flight: the one being read, the one being written, and one in between (see mx_strip)
+
 template <int T>
 struct MxGeom {
-    static constexpr int RPX = 32 * T + 4;          // right pixels staged per row (2-column window halo each side)
-    static constexpr int LPX = MX_M + 4;
-    static constexpr int RW = 2 * RPX, LW = 2 * LPX, WORDS = RW + LW;   // census words per staged row
-    static constexpr int ROUNDS = (WORDS + 63) / 64;
+    static constexpr int RPX = 32 * (MX_W + T - 1) + 4;   // right pixels staged per row for the workgroup (2-column window halo each side)
+    static constexpr int LPX = 32 * MX_W + 4;
+    static constexpr int PX = RPX + LPX;
+    static constexpr int WORDS = 2 * PX;                   // census words per staged row
+    static constexpr int ROUNDS = (WORDS + 64 * MX_W - 1) / (64 * MX_W);   // words per thread and row
+    static constexpr int FULL_ROUNDS = WORDS / (64 * MX_W);                // rounds in which every wavefront takes part
     // LDS image of a staged row: one plane per descriptor word (= per k-half of the matrix instruction), a pixel's
     // 32 fp4 values (16 bytes) at [word][pixel], right pixels first.  A 16-lane group of a 16-byte read then covers
-    // 256 consecutive bytes (with the two words of a pixel side by side it would hit every bank twice).  The planes
-    // are PLANE pixels apart, PLANE = 8 mod 16, so that the 8 + 8 lanes of a write group land in different banks; the
-    // lanes of the last staging round that hold no word write behind the planes.
-    static constexpr int PLANE = RPX + LPX + MX_PLANE_PAD;
-    static constexpr int SLOTS = 2 * PLANE + (ROUNDS * 64 - WORDS);
-    static_assert(MX_PLANE_PAD != 0 || PLANE % 16 == 8, "plane offset must alternate the bank halves");
+    // 256 consecutive bytes (with the two words of a pixel side by side it would hit every bank twice).  A write
+    // group of 8 lanes stores 4 pixels of each plane; the planes are PLANE pixels apart, PLANE = 4 mod 8, so that the two
+    // runs of 64 bytes land in different halves of the 32 banks a store sees.
+    static constexpr int PLANE = PX + (12 - PX % 8) % 8 + MX_PLANE_PAD;
+    static constexpr int SLOTS = 2 * PLANE;
+    static_assert(MX_PLANE_PAD != 0 || PLANE % 8 == 4, "plane offset must alternate the bank halves of a store");
 };
 
 // 32 descriptor bits -> 32 fp4 values: dword j holds bits j, j+4, .. j+28 (the same permutation on both operands).
@@ -99,45 +104,36 @@ __device__ __forceinline__ float mx_max3(float a, float b, float c) { float r; a
 template <int... Is, class F>
 __device__ __forceinline__ void mx_static_for(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
 
-// Matrix instruction after which staging unit v of the next row is issued.  Units: round g = v / 2 (entering row
-// g < T + 2, then the leaving row), half v & 1 of its expansion in the steady state (PER = 10 instructions per tile);
-// whole rounds before it (PER = 5).  Round g < T holds the right pixels tile g reads (and 4 that tile g - 1 reads),
-// round T the last 4 right pixels and left pixels, round T + 1 left pixels.  The entering row's operands of a tile are
-// all fetched by the tile's first instruction (they are fetched 4 ahead), the leaving row's by its sixth.
+// Matrix instruction of a row after which the workgroup meets: the first one of the last tile.  From then on the row
+// only needs operands it has fetched already or fetches from its own staged row, and the next row's image, which
+// every wavefront has finished writing by then, may be read.
 template <int T, bool STEADY>
-constexpr int mx_unit_step(int v) {
-    constexpr int R = T + 2;
-    const int g0 = STEADY ? v / 2 : v, half = STEADY ? v & 1 : 0;
-    const bool old = g0 >= R;
-    const int g = old ? g0 - R : g0;
-    if (STEADY) {
-        if (g == T + 1) return (old ? 3 : 1) + half;
-        if (g == T) return 10 * (T - 1) + (old ? 8 : 1) + half;
-        if (g == T - 1) return 10 * g + (old ? 6 : 3) + half;
-        return 10 * g + (old ? 7 : 5) + half;
-    }
-    if (g == T + 1) return old ? 2 : 1;
-    if (g == T) return 5 * (T - 1) + (old ? 4 : 1);
-    if (g == T - 1) return 5 * g + (old ? 3 : 2);
-    return 5 * g + (old ? 4 : 3);
-}
+constexpr int mx_meet_step() { return (STEADY ? 10 : 5) * (T - 1); }
+// Matrix instruction after which staging unit v (a round of the entering row, then the rounds of the leaving row) is
+// issued: spread over the instructions before the meeting, early enough that the operand wait of the instruction the
+// workgroup meets behind covers the unit's LDS write (LDS operations of a wavefront complete in order, and that
+// instruction's operand was fetched MX_P instructions ahead).
+template <int T, bool STEADY>
+constexpr int mx_unit_step(int v) { return 1 + v * (mx_meet_step<T, STEADY>() - MX_P - 1) / (2 * MxGeom<T>::ROUNDS); }
 
 template <int T>
 struct MxState {
     using G = MxGeom<T>;
-    static constexpr int RR = G::RW / 64;                    // staging rounds that hold right words only
     uint32_t wn[G::ROUNDS], wo[G::ROUNDS];                   // census words of the next row to stage (entering, leaving)
-    uint32_t roff[RR];                                       // rounds < RR: this lane's word offset in a right row
-    const uint32_t *src[G::ROUNDS - RR];                     // the other rounds: this lane's word in row 0 of the strip
-    uint32_t flip[G::ROUNDS - RR];                           // all ones where that word is a left word
-    int slot0, slot_last;                                    // where this lane's word of round 0 / of the last round goes in a staged row
-    uint32_t hx, hy;                                         // first half of the expansion under way
+    const uint32_t *src[G::ROUNDS];                          // this thread's word of staging round i in census row 0 of the strip
+    uint32_t flip[G::ROUNDS];                                // all ones where that word is a left word
+    int slot0;                                               // where this thread's word of round 0 goes in a staged row (round i: + 32 MX_W i)
+    bool tail_wave, tail_lane;                               // last, partial round: this wavefront takes part / this lane holds a word
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
     float pen_l[T], pen_r[16];                               // border blocks: what each view must not use (0 or -2^21)
     float *out;                                              // left map: this lane's pixel of the row being written
     float *part;                                             // right view: this lane's slot of the row being written
     long part_stride, out_stride;
 };
+
+// The workgroup's meeting point.  No wait is attached: what a wavefront must have finished (its staging writes) is
+// covered by the operand wait of the matrix instruction in front of it, and its pending global loads stay in flight.
+__device__ __forceinline__ void mx_meet() { asm volatile("s_barrier" ::: "memory"); }
 
 // Accumulator element i of tile u as the left view (L) or the right view sees it.
 template <int T, bool EDGE>
@@ -187,76 +183,69 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane) {
     *st.out = mx_decode(mx_max(z, zo));                      // lanes l and l ^ 16 write the same value to the same place
 }
 
-// One census row r.  Its operands are in buf_n / buf_o (staged while the previous row ran).  Between its matrix
-// instructions the wavefront stages row r+1 into the same buffers, behind the reads of row r (mx_unit_step), fetches the
-// words of row r+2 and, in the steady state (STEADY: the row
-// five rows up leaves the window, its products with the left operand negated are added too, and every row has an
-// output), picks the winners: a tile's accumulators are final from its last product until its first product of the
-// next row, so tiles 0 .. T-2 are read while later tiles of the same row run and tile T-1 while tile 0 of the next
-// row runs, followed by the lane reduction and the store of that previous row.
+// One census row r of a strip.  Its operands are in the staged rows cur_e (row r, entering the 5-row window) and cur_l
+// (row r-5, leaving it, left pixels negated); the pointers include this lane's pixel offset.  The first MX_P right
+// operands and the entering row's left operands (an) were fetched while the previous row ran.  Between its matrix
+// instructions the wavefront expands its share of rows r+1 and r-4 into the workgroup's next staged rows (stage_e,
+// stage_l), fetches the words of rows r+2 and r-3 and, in the steady state (STEADY: the row five rows up leaves the
+// window, its products with the left operand negated are added too, and every row has an output), picks the winners:
+// a tile's accumulators are final from its last product until its first product of the next row, so tiles 0 .. T-2 are
+// read while later tiles of the same row run and tile T-1 while tile 0 of the next row runs, followed by the lane
+// reduction and the store of that previous row.  After the first product of the last tile the workgroup meets; behind
+// that point the next row's left operands and first right operands are fetched from nxt_e.
 template <int T, bool STEADY, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], uint4 *buf_n, uint4 *buf_o, MxState<T> &st,
-                                       const uint32_t *__restrict__ right_new, const uint32_t *__restrict__ right_old,
+__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *cur_e, const uint4 *cur_l, const uint4 *nxt_e,
+                                       uint4 *stage_e, uint4 *stage_l, MxState<T> &st, mx_v8i (&an)[5], uint4 (&fb)[MX_P],
                                        long off_new, long off_old, int lane, int swap32) {
     using G = MxGeom<T>;
-    constexpr int PER = STEADY ? 10 : 5, S = T * PER, P = MX_P, RR = MxState<T>::RR;
-    constexpr int UNITS = STEADY ? 4 * G::ROUNDS : 2 * G::ROUNDS;     // staging work in halves of a round, or whole rounds
-    static_assert(G::ROUNDS == T + 2 && MX_P == 4, "the staging timetable assumes T + 2 rounds and operands fetched 4 ahead");
+    constexpr int PER = STEADY ? 10 : 5, S = T * PER, P = MX_P;
+    constexpr int MEET = mx_meet_step<T, STEADY>();
+    static_assert(S % P == 0 && S - P >= MEET && MEET - P - 1 >= 1, "operands of the next row are fetched behind the meeting point only, into the slots the row expects");
     static_assert(T >= 3, "the fold schedule needs three tiles");
-    const int n = lane & 31, h = lane >> 5;
     uint32_t c22;
     asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
     const uint32_t m88 = 0x88888888u;
-    mx_v8i an[5], ao[5];
+    mx_v8i ao[5];
+    if (STEADY) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        an[k] = mx_frag(buf_n[h * G::PLANE + G::RPX + n + k]);
-        if (STEADY) ao[k] = mx_frag(buf_o[h * G::PLANE + G::RPX + n + k]);
+        for (int k = 0; k < 5; ++k) ao[k] = mx_frag(cur_l[G::RPX + k]);
     }
-    auto right = [&](int s) -> uint4 {
-        const int t = s / PER, j = s % PER, k = j % 5;
-        return (j >= 5 ? buf_o : buf_n)[h * G::PLANE + 32 * t + n + k];
+    auto right = [&](int s) -> uint4 {               // right operand of matrix instruction s; s >= S: of the next row's instruction s - S
+        const bool next = s >= S;
+        const int s2 = next ? s - S : s, t = s2 / PER, j = s2 % PER, k = j % 5;
+        return (next ? nxt_e : j >= 5 ? cur_l : cur_e)[32 * t + k];
     };
-    uint4 fb[P];
-#pragma unroll
-    for (int s = 0; s < P; ++s) fb[s] = right(s);
     float rx[5];
     __builtin_amdgcn_sched_barrier(0);
     mx_static_for(std::make_integer_sequence<int, S>{}, [&](auto s_c) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value;
         constexpr int t = s / PER, j = s % PER, k = j % 5;
         const mx_v8i b = mx_frag(fb[s % P]);
-        if constexpr (s + P < S) fb[s % P] = right(s + P);
         acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(j >= 5 ? ao[k] : an[k], b, acc[t], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         asm volatile("" : "+v"(acc[t]));      // keeps the instruction at this place among the ordered statements around it
+        if constexpr (s == MEET) mx_meet();
+        fb[s % P] = right(s + P);
+        if constexpr (s >= MEET && s < MEET + 5) an[s - MEET] = mx_frag(nxt_e[G::RPX + (s - MEET)]);   // its last use was this instruction
 
-        // staging of the next row into the same buffers (LDS operations of a wavefront execute in order): a round of
-        // right pixels is overwritten once the tile that reads it has issued its reads, the left pixels (read at the
-        // start of the row) at once; mx_unit_step has the timetable
-        mx_static_for(std::make_integer_sequence<int, UNITS>{}, [&](auto v_c) __attribute__((always_inline)) {
+        // this thread's share of the next staged rows
+        mx_static_for(std::make_integer_sequence<int, 2 * G::ROUNDS>{}, [&](auto v_c) __attribute__((always_inline)) {
             constexpr int v = decltype(v_c)::value;
             if constexpr (mx_unit_step<T, STEADY>(v) == s && !(MX_X & 1)) {
-                constexpr int g = STEADY ? v / 2 : v;                 // round: entering row first, then the leaving row
-                constexpr bool old = g >= G::ROUNDS;
-                constexpr int i = old ? g - G::ROUNDS : g;
-                uint32_t w = old ? st.wo[i] : st.wn[i];
-                if constexpr (old && i >= RR) w ^= st.flip[i - RR];   // the leaving row's left words are complemented
-                if constexpr (!STEADY || (v & 1) == 0) {
-                    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(st.hx) : "v"(w << 3), "s"(m88), "v"(c22));
-                    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(st.hy) : "v"(w << 2), "s"(m88), "v"(c22));
-                }
-                if constexpr (!STEADY || (v & 1) == 1) {
+                constexpr bool old = v >= G::ROUNDS;                  // entering row first, then the leaving row
+                constexpr int i = old ? v - G::ROUNDS : v;
+                auto unit = [&](bool lane_has_word) __attribute__((always_inline)) {
+                    uint32_t w = old ? st.wo[i] : st.wn[i];
+                    if constexpr (old) w ^= st.flip[i];               // the leaving row's left words are complemented
                     uint4 e;
-                    e.x = st.hx; e.y = st.hy;
+                    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.x) : "v"(w << 3), "s"(m88), "v"(c22));
+                    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.y) : "v"(w << 2), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.z) : "v"(w << 1), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.w) : "v"(w), "s"(m88), "v"(c22));
-                    (old ? buf_o : buf_n)[i == G::ROUNDS - 1 ? st.slot_last : st.slot0 + i * 32] = e;
-                    if constexpr (i < RR) {
-                        if constexpr (old) st.wo[i] = right_old[st.roff[i]]; else st.wn[i] = right_new[st.roff[i]];
-                    } else {
-                        if constexpr (old) st.wo[i] = st.src[i - RR][off_old]; else st.wn[i] = st.src[i - RR][off_new];
-                    }
-                }
+                    if (lane_has_word) (old ? stage_l : stage_e)[st.slot0 + i * (32 * MX_W)] = e;
+                    if constexpr (old) st.wo[i] = st.src[i][off_old]; else st.wn[i] = st.src[i][off_new];
+                };
+                if constexpr (i < G::FULL_ROUNDS) unit(true);
+                else if (st.tail_wave) unit(st.tail_lane);
             }
         });
 
@@ -351,13 +340,19 @@ __device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<
     }
 }
 
-// Strip of one x-block: census rows y_lo-2 .. y_hi+1, output rows y_lo .. y_hi-1.
+// Strip of the workgroup's x-blocks: census rows y_lo-2 .. y_hi+1, output rows y_lo .. y_hi-1; this wavefront owns the
+// x-block whose first left column is xl0, the workgroup's first x-block starts at xl0_wg.
+//
+// Staged rows: MX_NBUF images, each an entering and a leaving row, used in turn.  Row r reads image r % 3 and
+// writes image (r + 1) % 3; a wavefront that is ahead of the others has passed the meeting point of row r - 1 at
+// least, so every wavefront has finished reading the image it overwrites (last read by row r - 2), and what it reads
+// behind the meeting point of row r (the next image) is complete.
 template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_strip(uint4 (&lds)[2][MxGeom<T>::SLOTS], const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
-                                         int cols, int max_disp, int xl0, int y_lo, int n_rows, int lane, float *__restrict__ disp,
+__device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
+                                         int cols, int max_disp, int xl0, int xl0_wg, int y_lo, int n_rows, int tid, float *__restrict__ disp,
                                          float *__restrict__ part_row0, long part_stride) {
     using G = MxGeom<T>;
-    constexpr int RR = MxState<T>::RR;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
     const int r0 = xl0 - 32 * (T - 1);               // right column of tile 0, lane 0
     const int swap32 = (lane ^ 32) * 4;
@@ -384,29 +379,25 @@ __device__ __forceinline__ void mx_strip(uint4 (&lds)[2][MxGeom<T>::SLOTS], cons
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.pen_r[i] = xl0 + (i & 3) + 8 * (i >> 2) + 4 * h <= cols - 6 ? 0.0f : -2097152.0f;
 
-    // staging: word q of a row is right word (r0 - 2) * 2 + q for q < RW, left word (xl0 - 2) * 2 + q - RW after it;
-    // words left of the frame and the padding of the last round are clamped: they only feed inadmissible pairs
+    // staging: word q of a staged row is right word (xl0_wg - 32 (T - 1) - 2) * 2 + q for q < 2 RPX, left word
+    // (xl0_wg - 2) * 2 + q - 2 RPX after it; thread tid takes the words tid, tid + 256, ...  Words outside the frame
+    // are clamped into it: left of the frame they only feed inadmissible pairs, right of it (the columns behind the
+    // last x-block of a workgroup that the frame does not fill) nothing reads them.
     const long row_words = (long)cols * 2;
     const uint32_t *const cl0 = cl + (long)(y_lo - 2) * row_words, *const cr0 = cr + (long)(y_lo - 2) * row_words;
 #pragma unroll
     for (int i = 0; i < G::ROUNDS; ++i) {
-        const int q = min(i * 64 + lane, G::WORDS - 1);
-        const bool is_left = q >= G::RW;
-        if (i < RR) {
-            st.roff[i < RR ? i : 0] = (uint32_t)max((r0 - 2) * 2 + q, 0);
-        } else {
-            st.src[i >= RR ? i - RR : 0] = is_left ? cl0 + (xl0 - 2) * 2 + (q - G::RW) : cr0 + max((r0 - 2) * 2 + q, 0);
-            st.flip[i >= RR ? i - RR : 0] = is_left ? 0xffffffffu : 0u;
-        }
+        const int q = min(i * (64 * MX_W) + tid, G::WORDS - 1);
+        const bool is_left = q >= 2 * G::RPX;
+        const long wr = min(max((long)(xl0_wg - 32 * (T - 1) - 2) * 2 + q, 0L), row_words - 1);
+        const long wl = min(max((long)(xl0_wg - 2) * 2 + (q - 2 * G::RPX), 0L), row_words - 1);
+        st.src[i] = is_left ? cl0 + wl : cr0 + wr;
+        st.flip[i] = is_left ? 0xffffffffu : 0u;
     }
-    auto word = [&](int i, int r) -> uint32_t {       // word of staging round i in census row r of the strip
-        return i < RR ? cr0[r * row_words + st.roff[i < RR ? i : 0]] : st.src[i >= RR ? i - RR : 0][r * row_words];
-    };
-    st.slot0 = (lane & 1) * G::PLANE + (lane >> 1);
-    {
-        const int q = (G::ROUNDS - 1) * 64 + lane;
-        st.slot_last = q < G::WORDS ? (q & 1) * G::PLANE + (q >> 1) : 2 * G::PLANE + (q - G::WORDS);
-    }
+    auto word = [&](int i, int r) -> uint32_t { return st.src[i][r * row_words]; };   // word of staging round i in census row r of the strip
+    st.slot0 = (tid & 1) * G::PLANE + (tid >> 1);
+    st.tail_wave = (G::ROUNDS - 1) * (64 * MX_W) + wave * 64 < G::WORDS;
+    st.tail_lane = (G::ROUNDS - 1) * (64 * MX_W) + tid < G::WORDS;
     const int last = n_rows - 1;
     const int i_out = lane & 15;
     st.out = disp + (long)y_lo * cols + xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h;
@@ -414,70 +405,91 @@ __device__ __forceinline__ void mx_strip(uint4 (&lds)[2][MxGeom<T>::SLOTS], cons
     st.part = part_row0 + n;
     st.part_stride = part_stride;
 
+    // image b: entering row at lds + 2 b SLOTS, leaving row behind it; a lane reads at its pixel offset `rd`
+    const int rd = h * G::PLANE + (xl0 - xl0_wg) + n;
+    auto img_e = [&](int b) -> uint4 * { return lds + (2 * b) * G::SLOTS; };
+    auto img_l = [&](int b) -> uint4 * { return lds + (2 * b + 1) * G::SLOTS; };
+
     // row 0 is staged here, every other row while its predecessor runs
     {
         uint32_t c22;
         asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
 #pragma unroll
-        for (int i = 0; i < G::ROUNDS; ++i) lds[0][i == G::ROUNDS - 1 ? st.slot_last : st.slot0 + i * 32] = mx_expand(word(i, 0), c22);
+        for (int i = 0; i < G::ROUNDS; ++i)
+            if (i < G::FULL_ROUNDS || st.tail_lane) img_e(0)[st.slot0 + i * (32 * MX_W)] = mx_expand(word(i, 0), c22);
 #pragma unroll
         for (int i = 0; i < G::ROUNDS; ++i) { st.wn[i] = word(i, 1); st.wo[i] = 0u; }
     }
+    __syncthreads();
+    mx_v8i an[5];
+    uint4 fb[MX_P];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) an[k] = mx_frag(img_e(0)[rd + G::RPX + k]);
+#pragma unroll
+    for (int s = 0; s < MX_P; ++s) fb[s] = img_e(0)[rd + s];          // tile 0, window columns 0 .. MX_P-1 (MX_P <= 5)
+    static_assert(MX_P <= 5, "the first operands of a row are those of its first tile's entering products");
+
     // row r stages row r+1 (entering) with row r-4 (leaving) and fetches the words of rows r+2 and r-3
+    int b_cur = 0, b_nxt = 1;
 #pragma unroll 1
     for (int r = 0; r < 5; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)max(r - 3, 0) * row_words;
-        mx_row<T, false, BOTH, EDGE>(acc, lds[0], lds[1], st, cr0 + on, cr0 + oo, on, oo, lane, swap32);
+        mx_row<T, false, BOTH, EDGE>(acc, img_e(b_cur) + rd, img_l(b_cur) + rd, img_e(b_nxt) + rd, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32);
+        b_cur = b_nxt;
+        b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
     }
     mx_first_output<T, BOTH, EDGE>(acc, st, swap32);
 #pragma unroll 1
     for (int r = 5; r < n_rows; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)(r - 3) * row_words;
-        mx_row<T, true, BOTH, EDGE>(acc, lds[0], lds[1], st, cr0 + on, cr0 + oo, on, oo, lane, swap32);
+        mx_row<T, true, BOTH, EDGE>(acc, img_e(b_cur) + rd, img_l(b_cur) + rd, img_e(b_nxt) + rd, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32);
+        b_cur = b_nxt;
+        b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
     }
     mx_last_output<T, BOTH, EDGE>(acc, st, lane, swap32);
 }
 
-// grid: (x-blocks, strips, frames), one wavefront per block.  x-block b owns output columns [xl0, xl0 + 32),
-// xl0 = min(2 + 32 b, cols - 34) (the last block is shifted left to end at column cols-3).
+// grid: (groups of MX_W x-blocks, strips, frames), MX_W wavefronts per block, one per x-block.  x-block b owns output
+// columns [xl0, xl0 + 32), xl0 = min(2 + 32 b, cols - 34) (the last block is shifted left to end at column cols-3);
+// a wavefront behind the last x-block repeats it (same results to the same places).
 // Requires cols >= 36, rows >= 5, max_disp <= 32 * (T - 1).
 // BOTH: also stores, for every output row and x-block, the right view's best key of each of the block's 32 T right
 // columns over the block's left columns: partial[frame][row][x-block][32 T] (svx_mx_right_disparity merges them).
 template <int T, bool BOTH>
-__global__ __launch_bounds__(64, T <= 5 ? 2 : 1) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
-                                                          int rows, int cols, int max_disp, int strip_rows,
+__global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
+                                                          int rows, int cols, int max_disp, int strip_rows, int n_xblocks,
                                                           float *__restrict__ disp_all, int write_border, float *__restrict__ partial) {
     using G = MxGeom<T>;
-    __shared__ uint4 lds[2][G::SLOTS];               // [entering row, leaving row][see MxGeom]
-    const int lane = threadIdx.x;
+    __shared__ uint4 lds[MX_NBUF * 2 * G::SLOTS];    // [image][entering row, leaving row][see MxGeom]
+    const int tid = threadIdx.x, lane = tid & 63;
     const int n = lane & 31, h = lane >> 5;
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
     unsigned wi = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     if ((total & 7u) == 0u) wi = (wi & 7u) * (total >> 3) + (wi >> 3);      // contiguous run of work items per XCD
-    const unsigned bx = wi % gridDim.x, by = (wi / gridDim.x) % gridDim.y, bz = wi / (gridDim.x * gridDim.y);
+    const unsigned gx = wi % gridDim.x, by = (wi / gridDim.x) % gridDim.y, bz = wi / (gridDim.x * gridDim.y);
     const long npx = (long)rows * cols;
     const uint32_t *cl = cl_all + bz * npx * 2;
     const uint32_t *cr = cr_all + bz * npx * 2;
     float *disp = disp_all + bz * npx;
-    const int n_xblocks = gridDim.x;
-    const int xl0 = min(2 + (int)bx * MX_M, cols - 2 - MX_M);
+    const int bx = min((int)gx * MX_W + __builtin_amdgcn_readfirstlane(tid >> 6), n_xblocks - 1);
+    const int xl0 = min(2 + bx * MX_M, cols - 2 - MX_M), xl0_wg = min(2 + (int)gx * MX_W * MX_M, cols - 2 - MX_M);
     const int y_lo = 2 + (int)by * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
     const int n_rows = y_hi - y_lo + 4;              // census rows y_lo-2 .. y_hi+1
     const long part_stride = (long)n_xblocks * (32 * T);
     float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)bx * (32 * T) : nullptr;
     // blocks in which the two views admit different pairs
     const bool edge = BOTH && (xl0 - 32 * (T - 1) < 5 || xl0 + MX_M - 1 > cols - 6);
-    if (edge) mx_strip<T, BOTH, BOTH>(lds, cl, cr, cols, max_disp, xl0, y_lo, n_rows, lane, disp, part_row0, part_stride);
-    else mx_strip<T, BOTH, false>(lds, cl, cr, cols, max_disp, xl0, y_lo, n_rows, lane, disp, part_row0, part_stride);
+    if (edge) mx_strip<T, BOTH, BOTH>(lds, cl, cr, cols, max_disp, xl0, xl0_wg, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    else mx_strip<T, BOTH, false>(lds, cl, cr, cols, max_disp, xl0, xl0_wg, y_lo, n_rows, tid, disp, part_row0, part_stride);
 
     if (write_border) {
         // rows outside [2, rows-2) over this block's columns, and the two border columns on either side
         const int ys = by == 0 ? 0 : y_lo, y_end = by == gridDim.y - 1 ? rows : y_hi;
         for (int y = ys + h; y < y_end; y += 2)
             if (y < 2 || y >= rows - 2) disp[(long)y * cols + xl0 + n] = 0.0f;
-        if ((int)bx == 0)
+        if (bx == 0)
             for (int y = ys + (lane >> 1); y < y_end; y += 32) disp[(long)y * cols + (lane & 1)] = 0.0f;
-        if ((int)bx == n_xblocks - 1)
+        if (bx == n_xblocks - 1)
             for (int y = ys + (lane >> 1); y < y_end; y += 32) disp[(long)y * cols + cols - 2 + (lane & 1)] = 0.0f;
     }
 }
@@ -549,11 +561,12 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
                         float *disparity, int write_border, float *partial) {
     const int T = mx_tiles(max_disp);
     // Strips: every strip re-reads 4 halo rows and starts with 5 rows that fill the window, but the grid should fill the
-    // chip a whole number of times (one wavefront per block; 8 or, with nine tiles, 4 of them fit a CU): take the
+    // chip a whole number of times (two workgroups or, with nine tiles, one fit a CU): take the
     // number of strips with the smallest (rounds of wavefronts) x (rows a wavefront walks).
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
-    const long slots = (long)cus * (T <= 5 ? 8 : 4), per_strip = (long)mx_xblocks(cols) * n_frames;
+    const int n_groups = (mx_xblocks(cols) + MX_W - 1) / MX_W;       // workgroups along x
+    const long slots = (long)cus * (T <= 5 ? 2 : 1), per_strip = (long)n_groups * n_frames;
     const int out_rows = rows - 4;
     int n_strips = 1;
     long best_cost = -1;
@@ -566,13 +579,14 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     const int forced_rows = svx_opt(ctx, SVX_OPT_MX_STRIP_ROWS);
     const int strip_rows = forced_rows > 0 ? forced_rows : (out_rows + n_strips - 1) / n_strips;
     n_strips = (out_rows + strip_rows - 1) / strip_rows;
-    dim3 grid(mx_xblocks(cols), n_strips, n_frames);
-    if (T == 9 && !partial) dense_wta_mx_kernel<9, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
-    else if (T == 9) dense_wta_mx_kernel<9, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
-    else if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
-    else if (T == 3) dense_wta_mx_kernel<3, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
-    else if (!partial) dense_wta_mx_kernel<5, false><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, nullptr);
-    else dense_wta_mx_kernel<5, true><<<grid, 64, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, disparity, write_border, partial);
+    const dim3 grid(n_groups, n_strips, n_frames), block(64 * MX_W);
+    const int nb = mx_xblocks(cols);
+    if (T == 9 && !partial) dense_wta_mx_kernel<9, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, nullptr);
+    else if (T == 9) dense_wta_mx_kernel<9, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, partial);
+    else if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, nullptr);
+    else if (T == 3) dense_wta_mx_kernel<3, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, partial);
+    else if (!partial) dense_wta_mx_kernel<5, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, nullptr);
+    else dense_wta_mx_kernel<5, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, partial);
     SVX_LAUNCH_CHECK(ctx, "dense_wta_mx_kernel");
     return SVX_OK;
 }

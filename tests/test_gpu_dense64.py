@@ -91,6 +91,19 @@ def test_dense_wta_matrix_matches_oracle(ctx, rows, cols, max_disp):
         assert np.array_equal(dr[f], want_r), (f, np.argwhere(dr[f] != want_r)[:5])
 
 
+@pytest.mark.parametrize("rows,cols,max_disp", [(40, 420, 64), (23, 300, 128), (30, 330, 256)])
+def test_dense_wta_matrix_close_costs(ctx, rows, cols, max_disp):
+    """Descriptors of real image texture: neighbouring disparities cost almost the same, so one wrong operand anywhere in
+    a window moves the winner (random descriptors with one planted match would not notice)."""
+    from stereovision_amd import synth
+    left, right, _ = synth.stereo_pair(rows, cols, min(max_disp, cols // 3), seed=rows)
+    cl, cr = O.census9x7(left), O.census9x7(right)
+    dl, dr = ctx.dense_wta_matrix(dev_u32(cl), dev_u32(cr), max_disp)
+    want_l, want_r = O.dense_wta_words(cl, cr, max_disp, 0), O.dense_wta_words(cl, cr, max_disp, 1)
+    assert np.array_equal(dl.cpu().numpy(), want_l), np.argwhere(dl.cpu().numpy() != want_l)[:5]
+    assert np.array_equal(dr.cpu().numpy(), want_r), np.argwhere(dr.cpu().numpy() != want_r)[:5]
+
+
 def test_dense_wta_matrix_refuses_what_it_does_not_cover(ctx):
     import stereovision_amd as S
     cl = dev_u32(np.zeros((1, 8, 30, 2), np.uint32))
