@@ -36,7 +36,9 @@ constexpr int MX_M = 32;                 // left columns per wavefront
 #define MX_MAX_DISP 256   // 3, 5 or 9 tiles of 32 right columns (17 tiles for 512 disparities spill: 27.5 against 13.3 ms at 4K)
 #endif
 
-constexpr int MX_W = 4;                  // wavefronts (x-blocks of 32 left columns) per workgroup: they share one staged image of the census rows
+#ifndef MX_W
+#define MX_W 4                           // wavefronts (x-blocks of 32 left columns) per workgroup: they share one staged image of the census rows
+#endif
 constexpr int MX_NBUF = 3;               // staged rows in flight: the one being read, the one being written, and one in between (see mx_strip)
 
 template <int T>
@@ -561,12 +563,12 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
                         float *disparity, int write_border, float *partial) {
     const int T = mx_tiles(max_disp);
     // Strips: every strip re-reads 4 halo rows and starts with 5 rows that fill the window, but the grid should fill the
-    // chip a whole number of times (two workgroups or, with nine tiles, one fit a CU): take the
+    // chip a whole number of times (8 wavefronts or, with nine tiles, 4 fit a CU): take the
     // number of strips with the smallest (rounds of wavefronts) x (rows a wavefront walks).
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
     const int n_groups = (mx_xblocks(cols) + MX_W - 1) / MX_W;       // workgroups along x
-    const long slots = (long)cus * (T <= 5 ? 2 : 1), per_strip = (long)n_groups * n_frames;
+    const long slots = (long)cus * ((T <= 5 ? 8 : 4) / MX_W > 0 ? (T <= 5 ? 8 : 4) / MX_W : 1), per_strip = (long)n_groups * n_frames;
     const int out_rows = rows - 4;
     int n_strips = 1;
     long best_cost = -1;
