@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--max-disp", type=int, default=128)
-    ap.add_argument("--cpu-frames", type=float, default=32.0, help="CPU-baseline work in frames of the 5x5 variant (the 9x7 variants take 1/4, with the check 1/8); 0 disables")
+    ap.add_argument("--cpu-frames", type=float, default=16.0, help="work of the scalar one-thread CPU leg in frames of the 5x5 variant (the 9x7 variants take 1/4, with the check 1/8); 0 disables both CPU legs")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--variant", choices=["9x7lr", "9x7", "5x5"], default="9x7lr")
     ap.add_argument("--lr-threshold", type=float, default=1.0)
@@ -112,49 +112,43 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_threads(left, right, D, variant, lr, lr_threshold, frames_per_thread):
-    """The same oracle routines on every host core of this process's share: plain threads, one band of rows each (ctypes
-    releases the GIL inside the C routines).  Returns the cpu_baseline-shaped dict."""
-    import threading
+def cpu_baseline_simd(ls, rs, D, variant, lr_threshold, seconds, got_all):
+    """The CPU baseline proper: the same step (census of both images, dense search, for 9x7lr both views + the check) in the
+    reference's style of optimisation (AVX2 + OpenMP, oracle/svx_cpu_simd.c, checked against the scalar oracle by the tests)
+    on every thread of the host share, on whole frames of the batch for about `seconds`.  Also compares every frame it
+    computes with the GPU's map of that frame."""
     import oracle_lib as O
-    rows, cols = left.shape
     T = host_threads()
-    if variant == "5x5":
-        cl, cr = O.census5x5(O.u8_to_s8(left)), O.census5x5(O.u8_to_s8(right))
-    else:
-        cl, cr = O.census9x7(left), O.census9x7(right)
-    total_rows = max(1, int(round(frames_per_thread * (rows - 4))))
-
-    def work():
-        done = 0
-        out = np.zeros((rows, cols), np.float32)
-        while done < total_rows:
-            take = min(rows - 4, total_rows - done)
-            if variant == "5x5":
-                O.lib.orc_dense_wta5x5_rows(cl.ctypes.data, cr.ctypes.data, rows, cols, D, out.ctypes.data, 2, 2 + take)
-            else:
-                w = O.dense_wta_words(cl, cr, D, 0, 2, 2 + take)
-                if lr:
-                    O.lr_check(w, O.dense_wta_words(cl, cr, D, 1, 2, 2 + take), lr_threshold, -1.0)
-            done += take
-
-    threads = [threading.Thread(target=work) for _ in range(T)]
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    rows, cols = ls[0].shape
+    lr = variant == "9x7lr"
+    done, same, t0 = 0, 0, time.perf_counter()
+    while True:
+        f = done % len(ls)
+        if variant == "5x5":
+            cl, cr = O.census5x5(O.u8_to_s8(ls[f])), O.census5x5(O.u8_to_s8(rs[f]))
+        else:
+            cl, cr = O.simd_census9x7(ls[f], T), O.simd_census9x7(rs[f], T)
+        dl, dr = O.simd_dense_wta_words(cl, cr, D, threads=T, right=lr)
+        out = O.simd_lr_check(dl, dr, lr_threshold, -1.0, T) if lr else dl
+        if done < len(ls):
+            same += int(np.array_equal(out, got_all[f]))
+        done += 1
+        if time.perf_counter() - t0 >= seconds and done >= min(len(ls), 4):
+            break
     secs = time.perf_counter() - t0
-    frames = T * total_rows / float(rows - 4)
+    checked = min(done, len(ls))
     return {
-        "value": round(rows * cols * D * frames / secs / 1e6, 2),
+        "value": round(rows * cols * D * done / secs / 1e6, 1),
         "unit": "Mpix*disp/s",
         "cores": T,
         "kind": "port",
         "cpu": cpu_model(),
-        "sample": "%.2f frames of %dx%d D=%d over %d threads (dense search rows only, census excluded), oracle/svx_oracle.c, %.1f s"
-                  % (frames, cols, rows, D, T, secs),
-    }
+        "sample": "%d whole frames of %dx%d D=%d (%s), AVX2 + OpenMP port oracle/svx_cpu_simd.c on %d threads, %.1f s"
+                  % (done, cols, rows, D, {"5x5": "5x5 census of both images (scalar) + dense 5x5-aggregated WTA",
+                                           "9x7": "9x7 census of both images + dense 5x5-aggregated WTA",
+                                           "9x7lr": "9x7 census of both images + dense 5x5-aggregated WTA in both views + left-right check"}[variant], T, secs),
+        "frames_equal_to_gpu": "%d/%d" % (same, checked),
+    }, same == checked
 
 
 def cpu_baseline(left, right, D, n_frames_work):
@@ -395,24 +389,27 @@ def main():
             parity = ("%d/%d frames bit-exact vs the oracle's committed hashes (tests/golden/bench_hashes.json)" % (F - len(bad), F)
                       if parity_ok else "MISMATCH vs the oracle's committed hashes on frames %s" % bad[:8])
 
-        # ---- CPU baseline (oracle port, 1 thread; rank 0 only), and the oracle itself on frame 0 where no hash applies ----
+        # ---- CPU baseline on the host (rank 0 only; the other ranks wait at the barrier meanwhile) ----
+        # cpu_baseline: the AVX2 + OpenMP port on every thread of the host share; cpu_baseline_scalar: the scalar oracle with the
+        # reference's loop structure (25 popcounts per pix*disp and descriptor word) on one thread, which also checks frame 0
+        # where no committed hash applies.
         cpu = None
-        cpu_all = None
+        cpu_scalar = None
         if args.cpu_frames > 0:
-            cpu_frames = args.cpu_frames if world == 1 else min(args.cpu_frames, 8.0)     # the other ranks wait at the barrier meanwhile
+            try:
+                cpu, simd_same = cpu_baseline_simd(ls, rs, D, variant, args.lr_threshold, 10.0 if world == 1 else 4.0, got_all)
+                cpu["reference_survey"] = REFERENCE_CPU_SURVEY
+                parity_ok = parity_ok and simd_same
+                if not simd_same:
+                    parity = "MISMATCH vs the CPU port (%s frames equal)" % cpu["frames_equal_to_gpu"]
+            except OSError as e:       # the library needs AVX2 and libgomp on the host
+                cpu = {"error": "%s: %s" % (type(e).__name__, e)}
+            scalar_frames = min(args.cpu_frames, 16.0) if world == 1 else min(args.cpu_frames, 4.0)
             if variant == "5x5":
-                cpu, want, nrows = cpu_baseline(ls[0], rs[0], D, cpu_frames)
+                cpu_scalar, want, nrows = cpu_baseline(ls[0], rs[0], D, scalar_frames)
             else:
-                cpu, want, nrows = cpu_baseline_9x7(ls[0], rs[0], D, cpu_frames / (8.0 if lr else 4.0), lr, args.lr_threshold)
-            cpu["cpu"] = cpu_model()
-            cpu["reference_survey"] = REFERENCE_CPU_SURVEY
-            if world == 1:
-                # the same port on every core of the host share, beside the one-thread figure
-                per_thread = {"5x5": 1.0, "9x7": 0.25, "9x7lr": 0.125}[variant] * cpu_frames / 4.0
-                try:
-                    cpu_all = cpu_baseline_threads(ls[0], rs[0], D, variant, lr, args.lr_threshold, per_thread)
-                except Exception as e:  # reported baseline only
-                    cpu_all = {"error": type(e).__name__}
+                cpu_scalar, want, nrows = cpu_baseline_9x7(ls[0], rs[0], D, scalar_frames / (8.0 if lr else 4.0), lr, args.lr_threshold)
+            cpu_scalar["cpu"] = cpu_model()
             same = bool(np.array_equal(got_all[0][2:2 + nrows], want[2:2 + nrows]))
             if hashes is None or not same:
                 parity_ok = parity_ok and same
@@ -444,7 +441,7 @@ def main():
                        "parallelism": "frames x%d" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "cpu_baseline_all_cores": cpu_all,
+            "cpu_baseline_scalar": cpu_scalar,
             "parity": parity,
             "gather_to_gpu0_ms": gather_ms,
         }

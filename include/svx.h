@@ -56,8 +56,8 @@ int svx_destroy(svx_ctx *ctx);
  * Callers that want concurrent streams create one context per stream. */
 int svx_set_stream(svx_ctx *ctx, void *hip_stream);
 int svx_synchronize(svx_ctx *ctx);
-/* Per-context tuning options (no counterpart in the reference).  Results never depend on them, only the choice of
- * kernel.  A new context starts from the built-in defaults, or from the environment variable named below when it is
+/* Per-context options (no counterpart in the reference).  Except for the last one results never depend on them, only
+ * the choice of kernel.  A new context starts from the built-in defaults, or from the environment variable named below when it is
  * set at svx_create time; svx_set_option overrides it for that context only.
  *   SVX_OPT_MATRIX_CORES     (SVX_MX)              -1 = matrix-core search where it is the faster kernel (default),
  *                                                  0 = never, 1 = wherever it applies
@@ -67,10 +67,13 @@ int svx_synchronize(svx_ctx *ctx);
  *   SVX_OPT_CENSUS97_PACKED  (SVX_CENSUS97_PACKED) 0 = one comparison per instruction in the 9x7 census tile kernel
  *   SVX_OPT_MX_STRIP_ROWS    (SVX_MX_STRIP_ROWS)   > 0 forces the output rows per strip of the matrix-core search
  *   SVX_OPT_STAGE_TIMES      (SVX_STAGE_TIMES)     1 = svx_high_perf_stereo synchronises at its stage marks and fills
- *                                                  svx_pipeline_stage_times (default 0: no synchronisation, times 0) */
+ *                                                  svx_pipeline_stage_times (default 0: no synchronisation, times 0)
+ * The one option that changes results:
+ *   SVX_OPT_PRIOR_BAND_RADIUS (SVX_PRIOR_BAND_RADIUS) radius of svx_high_perf_stereo's search around the plane prior
+ *                                                  (svx_cost_eval_band); default 0 = the reference's single disparity */
 enum svx_option {
     SVX_OPT_MATRIX_CORES = 0, SVX_OPT_LR_TWO_SWEEPS = 1, SVX_OPT_SWEEP_WAVES = 2, SVX_OPT_SWEEP_WAVES_BOTH = 3,
-    SVX_OPT_CENSUS97_PACKED = 4, SVX_OPT_MX_STRIP_ROWS = 5, SVX_OPT_STAGE_TIMES = 6, SVX_OPT_COUNT = 7
+    SVX_OPT_CENSUS97_PACKED = 4, SVX_OPT_MX_STRIP_ROWS = 5, SVX_OPT_STAGE_TIMES = 6, SVX_OPT_PRIOR_BAND_RADIUS = 7, SVX_OPT_COUNT = 8
 };
 int svx_set_option(svx_ctx *ctx, int option, int value);
 int svx_get_option(const svx_ctx *ctx, int option, int *value);   /* ctx NULL: the default a new context would get */
@@ -194,6 +197,17 @@ int svx_support_resampling(svx_ctx *ctx, const uint32_t *census_left, const uint
  * costs is in/out (the caller pre-fills it with tHigh, .cpp:573). */
 int svx_cost_eval(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
                   const int32_t *pts_xy, int n_pts, const float *disparities, int8_t *costs);
+
+/* Banded search around the plane prior (no counterpart in the reference: costEvaluation evaluates exactly one
+ * disparity per point; the only banded plane-prior search in its tree is libelas' SAD matcher, elas/elas.cpp:683-780,
+ * the model for this one).  d0 = (int)floor(prior + 0.5), the disparity svx_cost_eval evaluates, is admitted as there
+ * (x - d0 >= 2); the other candidates d0 + k, 0 < |k| <= radius, when 0 <= d0 + k, d0 + k < max_disp (max_disp <= 0:
+ * no upper bound) and x - (d0 + k) >= 2.  Ascending disparity, strict '<' (ties: smallest disparity).  costs(y,x) =
+ * the winner's single-pixel Hamming distance; disparities(y,x) becomes (float)winner when the winner is not d0 and is
+ * left as it is (fractional) otherwise, so svx_refine takes its result unchanged.  radius 0 is svx_cost_eval.
+ * SVX_OPT_PRIOR_BAND_RADIUS makes svx_high_perf_stereo use it with max_disp = maxDisp. */
+int svx_cost_eval_band(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                       const int32_t *pts_xy, int n_pts, float *disparities, int8_t *costs, int radius, int max_disp);
 
 /* ---- a11: accept / refine + occupancy grid --------------------------------
  * Replaces disparityRefinement, highPerfStereoLib.h:203-209, .cpp:44-86, and

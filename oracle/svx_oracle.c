@@ -246,6 +246,36 @@ ORC_API void orc_cost_eval(const uint32_t *cl, const uint32_t *cr, int rows, int
     }
 }
 
+/* Banded plane-prior search (build-defined extension of a10; the reference evaluates one disparity per point,
+ * highPerfStereoLib.cpp:20-41, and its only banded search around a plane prior is libelas' SAD matcher,
+ * elas/elas.cpp:683-780, which is the model for the band).  d0 = (int)floor(double(prior)+0.5) is evaluated exactly as
+ * orc_cost_eval does (admitted when x - d0 >= 2, no other bound).  The other candidates d0 + k, 0 < |k| <= radius, are
+ * admitted when 0 <= d0 + k, d0 + k < maxDisp (when maxDisp > 0) and x - (d0 + k) >= 2.  Candidates are visited in
+ * ascending disparity with a strict '<', so ties go to the smallest disparity.  No admitted candidate: the point is
+ * skipped.  Otherwise costs(y,x) = the winner's single-pixel Hamming distance, and when the winner is not d0 the prior
+ * becomes (float)winner; a winning d0 leaves the (fractional) prior as it is.  radius 0 is orc_cost_eval. */
+ORC_API void orc_cost_eval_band(const uint32_t *cl, const uint32_t *cr, int rows, int cols, const int32_t *pts_xy, int npts,
+                                float *disp, int8_t *costs, int radius, int maxDisp) {
+    const long n = (long)rows * cols;
+    for (int p = 0; p < npts; ++p) {
+        const int x = pts_xy[2 * p], y = pts_xy[2 * p + 1];
+        const long o = (long)y * cols + x;
+        const int d0 = (int)floor((double)disp[o] + 0.5);
+        int best = 1 << 30, best_d = 0, found = 0;
+        for (int k = -radius; k <= radius; ++k) {
+            const long d = (long)d0 + k;
+            const long xr = (long)x - d;
+            if (xr < 2) continue;
+            if (k != 0 && (d < 0 || (maxDisp > 0 && d >= maxDisp))) continue;
+            const int c = orc_popcount32(cl[o] ^ rd_u32(cr, n, (long)y * cols + xr));
+            if (c < best) { best = c; best_d = (int)d; found = 1; }
+        }
+        if (!found) continue;
+        costs[o] = (int8_t)best;
+        if (best_d != d0) disp[o] = (float)best_d;
+    }
+}
+
 /* ----------------------------------------------------------------- a11 --
  * highPerfStereo/highPerfStereoLib.cpp:44-86  disparityRefinement, with the
  * grid container of highPerfStereoLib.h:114-151.

@@ -26,6 +26,7 @@ from ._lib import (  # noqa: F401
     OPT_CENSUS97_PACKED,
     OPT_MX_STRIP_ROWS,
     OPT_STAGE_TIMES,
+    OPT_PRIOR_BAND_RADIUS,
     EXPORTS,
     DOMINANT_KERNEL,
     dense_kernel_name,

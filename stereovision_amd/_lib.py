@@ -10,7 +10,7 @@ EXFAST_NONMAX, EXFAST_THRESHOLD_ROUND_SAT = 1, 2
 VIEW_LEFT, VIEW_RIGHT = 0, 1
 WINDOW_5X6, WINDOW_5X5 = 0, 1
 # svx_option of include/svx.h
-OPT_MATRIX_CORES, OPT_LR_TWO_SWEEPS, OPT_SWEEP_WAVES, OPT_SWEEP_WAVES_BOTH, OPT_CENSUS97_PACKED, OPT_MX_STRIP_ROWS, OPT_STAGE_TIMES = range(7)
+OPT_MATRIX_CORES, OPT_LR_TWO_SWEEPS, OPT_SWEEP_WAVES, OPT_SWEEP_WAVES_BOTH, OPT_CENSUS97_PACKED, OPT_MX_STRIP_ROWS, OPT_STAGE_TIMES, OPT_PRIOR_BAND_RADIUS = range(8)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _vp = C.c_void_p
@@ -45,6 +45,7 @@ EXPORTS = {
     "svx_census_nxn_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "svx_support_resampling": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [_vp] * 7 + [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "svx_cost_eval": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "svx_cost_eval_band": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i]),
     "svx_refine": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, C.c_uint, _vp, _vp] + [_vp] * 7),
     "svx_plane_fit": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
     "svx_plane_prior_raster": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -449,6 +450,16 @@ class Context:
         self._call("svx_cost_eval", _dptr(census_left), _dptr(census_right), census_left.shape[0], census_left.shape[1],
                    _dptr(pts_xy), pts_xy.shape[0], _dptr(disparities), _dptr(costs))
         return costs
+
+    def cost_eval_band(self, census_left, census_right, pts_xy, disparities, costs, radius, max_disp):
+        """svx_cost_eval_band: in place on `disparities` (the prior) and `costs`."""
+        t = self._torch
+        _check_dev(census_left, t.int32, "census_left"); _check_dev(census_right, t.int32, "census_right")
+        _check_dev(pts_xy, t.int32, "pts_xy"); _check_dev(disparities, t.float32, "disparities")
+        _check_dev(costs, t.int8, "costs")
+        self._call("svx_cost_eval_band", _dptr(census_left), _dptr(census_right), census_left.shape[0], census_left.shape[1],
+                   _dptr(pts_xy), pts_xy.shape[0], _dptr(disparities), _dptr(costs), int(radius), int(max_disp))
+        return disparities, costs
 
     # ---- a11 ----
     def refine(self, pts_xy, disparities, costs, t_low, t_high, occ_grid_size, final_disp, final_costs):

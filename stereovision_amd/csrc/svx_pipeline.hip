@@ -223,7 +223,10 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         }
         clk.mark(6);
         SVX_HIP(ctx, hipMemsetAsync(costs, t_high & 0xff, n, ctx->stream));                             // .cpp:573
-        SVX_TRY(svx_cost_eval(ctx, cL, cR, R, Cc, pts, n_hg, disparities, costs));                      // .cpp:574
+        if (const int band = svx_opt(ctx, SVX_OPT_PRIOR_BAND_RADIUS); band > 0)                         // build extension: search d0 - band .. d0 + band
+            SVX_TRY(svx_cost_eval_band(ctx, cL, cR, R, Cc, pts, n_hg, disparities, costs, band, prm->maxDisp));
+        else
+            SVX_TRY(svx_cost_eval(ctx, cL, cR, R, Cc, pts, n_hg, disparities, costs));                  // .cpp:574
         SVX_TRY(svx_refine(ctx, pts, n_hg, disparities, costs, R, Cc, t_low, t_high, occ, final_disp, final_costs,
                            conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c));                       // .cpp:575-576
         clk.mark(7);

@@ -157,6 +157,50 @@ SVX_API int svx_cost_eval(svx_ctx *ctx, const uint32_t *census_left, const uint3
     return SVX_OK;
 }
 
+// Banded search around the plane prior (no counterpart in the reference, which evaluates the prior's own disparity
+// only; the band follows libelas' plane-prior matcher, elas/elas.cpp:683-780): candidates d0 - radius .. d0 + radius in
+// ascending order, strict '<'; d0 is admitted as costEvaluation admits it, the others when they are disparities of the
+// search range whose right pixel is at column 2 or beyond.  The prior takes the winner when that is not d0.
+__global__ __launch_bounds__(256) void cost_eval_band_kernel(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                                             const int32_t *__restrict__ pts_xy, int n_pts, float *__restrict__ disp,
+                                                             int8_t *__restrict__ costs, int radius, int max_disp) {
+    const long n = (long)rows * cols;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pts; p += gridDim.x * blockDim.x) {
+        const int2 pt = reinterpret_cast<const int2 *>(pts_xy)[p];
+        const int x = pt.x, y = pt.y;
+        if (x < 0 || x >= cols || y < 0 || y >= rows) continue;
+        const long o = (long)y * cols + x;
+        const int d0 = (int)floor((double)disp[o] + 0.5);
+        const uint32_t l = cl[o];
+        int best = 1 << 30, best_d = 0;
+        for (int k = -radius; k <= radius; ++k) {
+            const long d = (long)d0 + k, xr = (long)x - d;
+            if (xr < 2 || (k != 0 && (d < 0 || (max_disp > 0 && d >= max_disp)))) continue;
+            const int c = popc32(l ^ ld_guard_u32(cr, n, (long)y * cols + xr));
+            if (c < best) { best = c; best_d = (int)d; }
+        }
+        if (best == 1 << 30) continue;
+        costs[o] = (int8_t)best;
+        if (best_d != d0) disp[o] = (float)best_d;
+    }
+}
+
+SVX_API int svx_cost_eval_band(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
+                               const int32_t *pts_xy, int n_pts, float *disparities, int8_t *costs, int radius, int max_disp) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, census_left && census_right && disparities && costs, SVX_ERR_INVALID_ARG, "svx_cost_eval_band: null image pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_cost_eval_band: empty image");
+    SVX_REQUIRE(ctx, n_pts >= 0 && radius >= 0 && radius <= 1024, SVX_ERR_INVALID_ARG, "svx_cost_eval_band: bad point count or radius");
+    if (n_pts == 0) return SVX_OK;
+    SVX_REQUIRE(ctx, pts_xy != nullptr, SVX_ERR_INVALID_ARG, "svx_cost_eval_band: null point list");
+    unsigned grid = svx_cdiv(n_pts, 256);
+    if (grid > 4096) grid = 4096;
+    cost_eval_band_kernel<<<grid, 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, pts_xy, n_pts, disparities, costs, radius, max_disp);
+    SVX_LAUNCH_CHECK(ctx, "cost_eval_band_kernel");
+    return SVX_OK;
+}
+
 // --------------------------------------------------------------- a11 -----
 // Per-point accept step plus per-cell winners.  A sequential scan with strict
 // compares keeps, per cell, the lowest cost below tLow (confident support) and

@@ -35,6 +35,7 @@ lib.orc_dense_wta5x5.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p]
 lib.orc_dense_wta5x5_rows.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int]
 lib.orc_epipolar_match.argtypes = [_p, _p] + [C.c_int] * 7 + [_p, _p]
 lib.orc_cost_eval.argtypes = [_p, _p, C.c_int, C.c_int, _p, C.c_int, _p, _p]
+lib.orc_cost_eval_band.argtypes = [_p, _p, C.c_int, C.c_int, _p, C.c_int, _p, _p, C.c_int, C.c_int]
 lib.orc_refine.argtypes = [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint] + [_p] * 9
 lib.orc_sparse_match.restype = C.c_int
 lib.orc_sparse_match.argtypes = [_p, _p, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int,
@@ -125,6 +126,14 @@ def cost_eval(cl, cr, pts_xy, disp, costs):
     pts_xy = np.ascontiguousarray(pts_xy, dtype=np.int32)
     lib.orc_cost_eval(_ptr(cl), _ptr(cr), rows, cols, _ptr(pts_xy), len(pts_xy), _ptr(disp), _ptr(costs))
     return costs
+
+
+def cost_eval_band(cl, cr, pts_xy, disp, costs, radius, max_disp):
+    """In place on disp (the prior) and costs."""
+    rows, cols = cl.shape
+    pts_xy = np.ascontiguousarray(pts_xy, dtype=np.int32)
+    lib.orc_cost_eval_band(_ptr(cl), _ptr(cr), rows, cols, _ptr(pts_xy), len(pts_xy), _ptr(disp), _ptr(costs), int(radius), int(max_disp))
+    return disp, costs
 
 
 def refine(pts_xy, disp, costs, t_low, t_high, grid, final_disp, final_costs):
@@ -365,3 +374,51 @@ def kat_images():
             right[y, x] = pix(y, x)
             left[y, x] = pix(y, x - d) if x >= d else pix(y + 1, x + 50)
     return left, right
+
+
+# ---- the SIMD + OpenMP CPU baseline (oracle/svx_cpu_simd.c), checked against the routines above ----
+def _load_simd():
+    so = os.path.join(_ORACLE_DIR, "liboracle_simd.so")
+    src = os.path.join(_ORACLE_DIR, "svx_cpu_simd.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "liboracle_simd.so"], stdout=subprocess.DEVNULL)
+    s = C.CDLL(so)
+    s.simd_census9x7.argtypes = [_p, C.c_int, C.c_int, _p, C.c_int]
+    s.simd_dense_wta_words.argtypes = [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int]
+    s.simd_lr_check.argtypes = [_p, _p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+    s.simd_max_threads.restype = C.c_int
+    return s
+
+
+_simd = None
+
+
+def simd():
+    global _simd
+    if _simd is None:
+        _simd = _load_simd()
+    return _simd
+
+
+def simd_census9x7(img, threads=1):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros(img.shape + (2,), np.uint32)
+    simd().simd_census9x7(_ptr(img), img.shape[0], img.shape[1], _ptr(out), threads)
+    return out
+
+
+def simd_dense_wta_words(cl, cr, max_disp, threads=1, left=True, right=True, y0=0, y1=None):
+    cl = np.ascontiguousarray(cl, dtype=np.uint32); cr = np.ascontiguousarray(cr, dtype=np.uint32)
+    rows, cols = cl.shape[0], cl.shape[1]
+    words = cl.shape[2] if cl.ndim == 3 else 1
+    dl = np.zeros((rows, cols), np.float32) if left else None
+    dr = np.zeros((rows, cols), np.float32) if right else None
+    simd().simd_dense_wta_words(_ptr(cl), _ptr(cr), rows, cols, words, max_disp, _ptr(dl) if left else None, _ptr(dr) if right else None,
+                                y0, rows if y1 is None else y1, threads)
+    return dl, dr
+
+
+def simd_lr_check(dl, dr, threshold, invalid=-1.0, threads=1):
+    out = np.ascontiguousarray(dl, dtype=np.float32).copy()
+    simd().simd_lr_check(_ptr(out), _ptr(np.ascontiguousarray(dr, dtype=np.float32)), out.shape[0], out.shape[1], threshold, invalid, threads)
+    return out

@@ -9,7 +9,7 @@ import numpy as np
 import oracle_lib as O
 
 
-def high_perf_stereo(left, right, p, disparity_map, triangulate):
+def high_perf_stereo(left, right, p, disparity_map, triangulate, band_radius=0):
     """left/right: [rows, cols] uint8; p: any object with StereoParameters' field names; disparity_map: [rows, cols]
     float32, updated in place.  Returns (points [n,2] int32, info dict)."""
     assert left.shape == right.shape == disparity_map.shape                     # .cpp:187-191
@@ -60,7 +60,10 @@ def high_perf_stereo(left, right, p, disparity_map, triangulate):
                     abc[t] = O.plane_fit([[v[k, 0], v[k, 1], disparities[v[k, 1], v[k, 0]]] for k in range(3)])
                 O.plane_prior_raster(txy, abc, rows, cols, disparities)
         costs = np.full((rows, cols), p.tHigh, np.int8)                         # .cpp:573
-        O.cost_eval(cl, cr, pts, disparities, costs)                            # .cpp:574
+        if band_radius > 0:                                                     # build extension: banded search around the prior
+            O.cost_eval_band(cl, cr, pts, disparities, costs, band_radius, p.maxDisp)
+        else:
+            O.cost_eval(cl, cr, pts, disparities, costs)                        # .cpp:574
         g = O.refine(pts, disparities, costs, p.tLow, p.tHigh, occ, final_disp, final_costs)   # .cpp:575-576
         if it != p.nIters:                                                      # .cpp:616-621
             nxy, _ = O.support_resampling(cl, cr, g, 5, p.costAggrWindowSize, p.tLow, p.tHigh, p.maxDisp, disparities)

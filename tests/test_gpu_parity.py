@@ -255,6 +255,35 @@ def test_cost_eval_and_refine(ctx, rows, cols, grid):
     assert np.array_equal(fc_g.cpu().numpy(), fc_w)
 
 
+@pytest.mark.parametrize("rows,cols,radius,max_disp", [(32, 64, 0, 16), (32, 64, 1, 16), (50, 130, 3, 40), (40, 96, 8, 0), (33, 70, 40, 24)])
+def test_cost_eval_band(ctx, rows, cols, radius, max_disp):
+    """Banded search around the prior: radius 0 is costEvaluation; otherwise cost and (where a neighbour wins) the prior
+    change exactly as the oracle's definition says, also for priors that are negative or point far outside the row."""
+    cl, cr, prior, pts = _prior_case(rows, cols, rows + radius, 0.4)
+    rng = np.random.default_rng(radius)
+    prior = prior.copy()
+    idx = rng.integers(0, prior.size, size=60)
+    prior.reshape(-1)[idx] = rng.choice(np.array([-3.4, -0.5, 0.49, 1e4, -1e4, 7.5], np.float32), size=60)
+    t_high = 10
+    prior_w, costs_w = prior.copy(), np.full((rows, cols), t_high, np.int8)
+    O.cost_eval_band(cl, cr, pts, prior_w, costs_w, radius, max_disp)
+    prior_g, costs_g = ctx.cost_eval_band(dev_u32(cl), dev_u32(cr), dev(pts), dev(prior), dev(np.full((rows, cols), t_high, np.int8)), radius, max_disp)
+    assert np.array_equal(costs_g.cpu().numpy(), costs_w)
+    assert np.array_equal(prior_g.cpu().numpy().view(np.uint32), prior_w.view(np.uint32))
+    if radius == 0:
+        plain = np.full((rows, cols), t_high, np.int8)
+        O.cost_eval(cl, cr, pts, prior, plain)
+        assert np.array_equal(costs_w, plain) and np.array_equal(prior_w.view(np.uint32), prior.view(np.uint32))
+    else:
+        assert (prior_w != prior).any()
+        # a wider band never raises the cost of a point
+        plain = np.full((rows, cols), t_high, np.int8)
+        O.cost_eval(cl, cr, pts, prior, plain)
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        centre_ok = (xx - np.floor(prior.astype(np.float64) + 0.5)) >= 2      # where costEvaluation itself evaluates the point
+        assert (costs_w <= plain)[centre_ok].all()
+
+
 def test_refine_empty_point_list(ctx):
     rows, cols = 20, 40
     prior = dev(np.zeros((rows, cols), np.float32)); costs = dev(np.full((rows, cols), 10, np.int8))

@@ -27,13 +27,36 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def run_both(ctx, left, right, params, init=0.0):
+def run_both(ctx, left, right, params, init=0.0, band_radius=0):
     import stereovision_amd as S
     dm = np.full(left.shape, init, np.float32)
-    want_pts, info = OP.high_perf_stereo(left, right, params, dm, S.delaunay)
+    want_pts, info = OP.high_perf_stereo(left, right, params, dm, S.delaunay, band_radius)
     got_map = dev(np.full(left.shape, init, np.float32))
-    got_pts = ctx.high_perf_stereo(dev(left), dev(right), params, got_map)
+    ctx.set_option(S.OPT_PRIOR_BAND_RADIUS, band_radius)
+    try:
+        got_pts = ctx.high_perf_stereo(dev(left), dev(right), params, got_map)
+    finally:
+        ctx.set_option(S.OPT_PRIOR_BAND_RADIUS, 0)
     return got_pts, got_map.cpu().numpy(), want_pts, dm, info
+
+
+@pytest.mark.parametrize("rows,cols,seed,radius,over", [
+    (375, 1242, 11, 2, dict(maxDisp=70, nIters=2)),
+    (120, 250, 12, 5, dict(maxDisp=32, nIters=3, gradThreshold=30)),
+    (64, 64, 13, 1, dict(maxDisp=16, nIters=2, gradThreshold=20, costAggrWindowSize=5)),
+])
+def test_pipeline_with_banded_prior_search(ctx, rows, cols, seed, radius, over):
+    """The pipeline with the search around the plane prior widened to d0 +- radius (a build extension, off by default):
+    same composition on both sides, bit for bit; and the band changes the result (so the option is really taken)."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    p = S.StereoParameters.reference_defaults(**over)
+    left, right, _ = synth.stereo_pair(rows, cols, min(p.maxDisp, 64), seed)
+    got_pts, got_map, want_pts, want_map, info = run_both(ctx, left, right, p, band_radius=radius)
+    assert np.array_equal(got_pts, want_pts), info
+    assert np.array_equal(got_map, want_map)
+    _, plain_map, _, _, _ = run_both(ctx, left, right, p)
+    assert not np.array_equal(plain_map, got_map)
 
 
 @pytest.mark.parametrize("rows,cols,seed,over", [

@@ -91,6 +91,35 @@ def test_plane_prior_path(census_pair):
         assert (d, c) == (e["d"], e["cost"]), e
 
 
+def test_banded_prior_search_radius_0_is_the_pinned_cost_evaluation(census_pair):
+    """orc_cost_eval_band (a build extension) at radius 0 reproduces the reference's known-answer hash of costEvaluation and
+    leaves the prior untouched; at radius 2 no point gets worse and the winners obey the definition (brute force here)."""
+    cl, cr = census_pair
+    k = KAT["plane_prior_path"]
+    R, Cc = cl.shape
+    yy, xx = np.mgrid[0:R, 0:Cc]
+    prior = ((np.float32(3.2) + np.float32(0.11) * yy.astype(np.float32)) + np.float32(0.004) * xx.astype(np.float32)).astype(np.float32)
+    pts = [(x, y) for y in range(2, R - 2) for x in range(2, Cc - 2) if (x + 2 * y) % 3 == 0]
+    costs0, prior0 = np.full((R, Cc), k["costs_prefill"], np.int8), prior.copy()
+    O.cost_eval_band(cl, cr, pts, prior0, costs0, 0, 16)
+    assert O.fnv(costs0) == k["fnv_costs_i8"] and np.array_equal(prior0, prior)
+    costs2, prior2 = np.full((R, Cc), k["costs_prefill"], np.int8), prior.copy()
+    O.cost_eval_band(cl, cr, pts, prior2, costs2, 2, 16)
+    d0_all = np.floor(prior.astype(np.float64) + 0.5).astype(np.int64)
+    centre_ok = (xx - d0_all) >= 2                      # where costEvaluation itself evaluates the point
+    assert (costs2 <= costs0)[centre_ok].all() and (costs2 < costs0).any()
+    for x, y in pts[::7]:
+        d0 = int(np.floor(np.float64(prior[y, x]) + 0.5))
+        cands = [d for d in range(d0 - 2, d0 + 3) if x - d >= 2 and (d == d0 or 0 <= d < 16)]
+        cost = {d: bin(int(cl[y, x]) ^ int(cr[y, x - d])).count("1") for d in cands}
+        if not cands:
+            assert costs2[y, x] == k["costs_prefill"]
+            continue
+        best = min(cands, key=lambda d: (cost[d], d))
+        assert costs2[y, x] == cost[best]
+        assert prior2[y, x] == (prior[y, x] if best == d0 else np.float32(best))
+
+
 def test_sse_vs_generic_mapping():
     rng = np.random.default_rng(7)
     img = rng.integers(-128, 128, size=(40, 48), dtype=np.int8)
