@@ -452,6 +452,14 @@ typedef struct svx_stereo_parameters {
 int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols,
                          const svx_stereo_parameters *parameters, float *disparity_map,
                          int32_t *points_xy_host, int capacity, int *n_points);
+/* svx_high_perf_stereo for n_frames pairs (frames back to back in left, right and disparity_maps; frame f's points at
+ * points_xy_host + 2 f capacity_per_frame, its count in n_points_host[f]) on n_threads host threads (<= 0: 4), each with
+ * a context and stream of its own inside `ctx`: frames are independent and a frame's host share (the triangulation)
+ * limits one thread, so this is how one GPU is kept busy.  Same results as n_frames single calls.  No counterpart in the
+ * reference (its callers loop over pairs on one thread).  Synchronous. */
+int svx_high_perf_stereo_batch(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
+                               const svx_stereo_parameters *parameters, float *disparity_maps, int32_t *points_xy_host,
+                               int capacity_per_frame, int *n_points_host, int n_threads);
 /* Wall-clock milliseconds of the stages of the context's last svx_high_perf_stereo call, in the spirit of the
  * per-stage table the reference's demo prints (highPerfStereo/highPerfStereo.cpp:97-99, :591-595):
  * [0] crop + equalisation, [1] gradient + high-gradient set, [2] row alterations + exFAST (both images),

@@ -77,6 +77,7 @@ EXPORTS = {
     "svx_kinect_evaluate": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svx_write_point_cloud_txt": (_i, [_vp, C.c_char_p, _vp, _vp, _i, _vp]),
     "svx_high_perf_stereo": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
+    "svx_high_perf_stereo_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "svx_pipeline_stage_times": (_i, [_vp, _vp, _i]),
     "svx_probe_valu_rate": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double)]),
     "svx_probe_both_views_sweep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -624,6 +625,21 @@ class Context:
         self._call("svx_high_perf_stereo", _dptr(left), _dptr(right), rows, cols, C.byref(params), _dptr(disparity_map),
                    pts.ctypes.data_as(_vp), cap, C.byref(n))
         return pts[:min(n.value, cap)].copy()
+
+    def high_perf_stereo_batch(self, left, right, params, disparity_maps, n_threads=4):
+        """svx_high_perf_stereo_batch on [frames, rows, cols] batches: disparity_maps updated in place; returns one [n, 2]
+        int32 point array per frame."""
+        t = self._torch
+        _check_dev(left, t.uint8, "left"); _check_dev(right, t.uint8, "right"); _check_dev(disparity_maps, t.float32, "disparity_maps")
+        if left.dim() != 3 or left.shape != right.shape or left.shape != disparity_maps.shape:
+            raise SvxError(-2, "Input images do not have the same dimensions!")
+        f, rows, cols = left.shape
+        cap = 2 * rows * cols
+        pts = np.zeros((f, cap, 2), np.int32)
+        n = (_i * f)()
+        self._call("svx_high_perf_stereo_batch", _dptr(left), _dptr(right), rows, cols, f, C.byref(params), _dptr(disparity_maps),
+                   pts.ctypes.data_as(_vp), cap, n, int(n_threads))
+        return [pts[i, :min(n[i], cap)].copy() for i in range(f)]
 
     PIPELINE_STAGES = ("crop+equalise", "gradient+points", "alter+exFAST", "census", "sparse match", "support upload",
                        "mesh+prior", "cost+refine", "resampling", "finalise")

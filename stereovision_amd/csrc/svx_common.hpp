@@ -21,6 +21,9 @@ struct svx_ctx {
     size_t arena_bytes;
     void *tri;                              // triangle corners and planes of the mesh prior, kept between calls
     size_t tri_bytes;
+    svx_ctx **workers;                      // svx_high_perf_stereo_batch: one context (and stream) per host thread, kept between calls
+    int n_workers;
+    hipStream_t own_stream;                 // a worker context's own stream (null for a caller's context)
     void *static_scratch;                   // this device's address of the code object's fixed scratch array (svx_dense.hip)
     hipEvent_t pinned_read;                 // recorded behind the last asynchronous copy out of `pinned`
     bool pinned_busy;

@@ -140,6 +140,9 @@ SVX_API int svx_create(int device, svx_ctx **out) {
     c->pinned_read = nullptr;
     c->pinned_busy = false;
     for (int o = 0; o < SVX_OPT_COUNT; ++o) c->opt[o] = svx_option_default(o);
+    c->workers = nullptr;
+    c->n_workers = 0;
+    c->own_stream = nullptr;
     c->static_scratch = nullptr;
     (void)svx_static_scratch_locate(c);     // on failure the pointer stays null and only the allocation-free entry point refuses to run
     c->err[0] = 0;
@@ -150,7 +153,10 @@ SVX_API int svx_create(int device, svx_ctx **out) {
 SVX_API int svx_destroy(svx_ctx *ctx) {
     if (!ctx) return SVX_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < ctx->n_workers; ++i) (void)svx_destroy(ctx->workers[i]);
+    free(ctx->workers);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->tri) (void)hipFree(ctx->tri);

@@ -4,7 +4,10 @@
 // as the reference's host code does.
 #include "svx_common.hpp"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -266,6 +269,59 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         points_xy_host[2 * (size_t)(n_hg + i) + 1] = sup[2 * i + 1];
     }
     clk.mark(9);
+    return SVX_OK;
+}
+
+// Frames are independent, and a frame's host share (the triangulation above all) is what limits one host thread: the
+// batch entry point runs svx_high_perf_stereo on n_threads host threads, each with a context and a stream of its own
+// (kept in the caller's context between calls), which take the frames in turn.
+SVX_API int svx_high_perf_stereo_batch(svx_ctx *ctx, const uint8_t *left, const uint8_t *right, int rows, int cols, int n_frames,
+                                       const svx_stereo_parameters *prm, float *disparity_maps, int32_t *points_xy_host,
+                                       int capacity_per_frame, int *n_points_host, int n_threads) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, left && right, SVX_ERR_EMPTY, "Input images are empty!");
+    SVX_REQUIRE(ctx, prm && disparity_maps && n_points_host, SVX_ERR_INVALID_ARG, "svx_high_perf_stereo_batch: null pointer");
+    SVX_REQUIRE(ctx, n_frames >= 1 && capacity_per_frame >= 0 && (capacity_per_frame == 0 || points_xy_host), SVX_ERR_INVALID_ARG,
+                "svx_high_perf_stereo_batch: bad frame count or point buffer");
+    if (n_threads <= 0) n_threads = 4;
+    n_threads = std::min(std::min(n_threads, n_frames), 64);
+    if (n_threads > ctx->n_workers) {
+        svx_ctx **w = (svx_ctx **)realloc(ctx->workers, sizeof(svx_ctx *) * (size_t)n_threads);
+        if (!w) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo_batch: worker table");
+        ctx->workers = w;
+        while (ctx->n_workers < n_threads) {
+            svx_ctx *c = nullptr;
+            rc = svx_create(ctx->device, &c);
+            if (rc) return svx_fail(ctx, rc, "svx_high_perf_stereo_batch: worker context: %s", svx_strerror(rc));
+            if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+                (void)svx_destroy(c);
+                return svx_fail(ctx, SVX_ERR_HIP, "svx_high_perf_stereo_batch: worker stream");
+            }
+            c->stream = c->own_stream;
+            ctx->workers[ctx->n_workers++] = c;
+        }
+    }
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));        // the inputs may still be in the making on the caller's stream
+    const size_t n = (size_t)rows * cols;
+    std::atomic<int> next(0), first_error(0);
+    std::vector<int> codes(n_threads, SVX_OK);
+    auto work = [&](int t) {
+        svx_ctx *c = ctx->workers[t];
+        for (int o = 0; o < SVX_OPT_COUNT; ++o) c->opt[o] = ctx->opt[o];
+        for (int f = next.fetch_add(1); f < n_frames && !first_error.load(); f = next.fetch_add(1)) {
+            const int r = svx_high_perf_stereo(c, left + f * n, right + f * n, rows, cols, prm, disparity_maps + f * n,
+                                               points_xy_host ? points_xy_host + 2 * (size_t)f * capacity_per_frame : nullptr,
+                                               capacity_per_frame, n_points_host + f);
+            if (r) { codes[t] = r; first_error.store(1); }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < n_threads; ++t) threads.emplace_back(work, t);
+    work(0);
+    for (auto &th : threads) th.join();
+    for (int t = 0; t < n_threads; ++t)
+        if (codes[t]) return svx_fail(ctx, codes[t], "svx_high_perf_stereo_batch: %s", ctx->workers[t]->err);
     return SVX_OK;
 }
 

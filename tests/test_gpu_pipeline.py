@@ -121,3 +121,21 @@ def test_pipeline_keeps_caller_values_and_errors(ctx):
     tiny = dev(np.zeros((8, 8), np.uint8))
     with pytest.raises(S.SvxError):
         ctx.high_perf_stereo(tiny, tiny, p, dev(np.zeros((8, 8), np.float32)))
+
+
+def test_pipeline_batch_equals_single_calls(ctx):
+    """svx_high_perf_stereo_batch (host threads with a context and stream each) against one call per frame: same maps, same
+    points, for more frames than threads and for a second call that reuses the worker contexts."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    rows, cols, frames = 120, 250, 7
+    p = S.StereoParameters.reference_defaults(maxDisp=32, nIters=2, gradThreshold=30)
+    ls, rs = synth.stereo_batch(rows, cols, 32, frames, seed0=50)
+    left, right = dev(ls), dev(rs)
+    want_maps = torch.zeros((frames, rows, cols), dtype=torch.float32, device="cuda")
+    want_pts = [ctx.high_perf_stereo(left[f], right[f], p, want_maps[f]) for f in range(frames)]
+    for threads in (3, 2, 16):
+        maps = torch.zeros((frames, rows, cols), dtype=torch.float32, device="cuda")
+        pts = ctx.high_perf_stereo_batch(left, right, p, maps, n_threads=threads)
+        assert torch.equal(maps, want_maps)
+        assert len(pts) == frames and all(np.array_equal(a, b) for a, b in zip(pts, want_pts))

@@ -46,6 +46,19 @@ def main():
             OP.high_perf_stereo(pairs[0][0], pairs[0][1], p, dm, S.delaunay)
             rec["cpu_oracle_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3, 1)
         print(json.dumps(rec), flush=True)
+    # the batch entry point: host threads inside the library, a context and a stream each
+    p = S.StereoParameters.reference_defaults(maxDisp=70, nIters=2)
+    ls, rs = synth.stereo_batch(rows, cols, 64, 32, seed0=0)
+    left, right = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
+    maps = torch.zeros((32, rows, cols), dtype=torch.float32, device="cuda")
+    for T in (1, 2, 4, 8, 16):
+        ctx.high_perf_stereo_batch(left, right, p, maps, n_threads=T)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.high_perf_stereo_batch(left, right, p, maps, n_threads=T)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"pipeline": "svx_high_perf_stereo_batch", "nIters": 2, "host_threads": T, "frames": 32,
+                          "ms_per_frame": round(dt * 1e3 / 32, 2), "frames_per_s": round(32 / dt, 1)}), flush=True)
     ctx.close()
     # Frames are independent: host threads with a context each (the host share of a frame, the triangulation, is what
     # limits one thread) keep one GPU busy.  ctypes releases the interpreter lock during a call.
