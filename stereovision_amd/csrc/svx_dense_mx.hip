@@ -125,7 +125,6 @@ struct MxState {
     const uint32_t *src[G::ROUNDS];                          // this thread's word of staging round i in census row 0 of the strip
     uint32_t flip[G::ROUNDS];                                // all ones where that word is a left word
     int slot0;                                               // where this thread's word of round 0 goes in a staged row (round i: + 32 MX_W i)
-    int dead;                                                // border blocks: tiles 0 .. dead-1 lie left of the frame and are skipped
     bool tail_wave, tail_lane;                               // last, partial round: this wavefront takes part / this lane holds a word
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
     float pen_l[T], pen_r[16];                               // border blocks: what each view must not use (0 or -2^21)
@@ -223,14 +222,11 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *cur_e, co
     mx_static_for(std::make_integer_sequence<int, S>{}, [&](auto s_c) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value;
         constexpr int t = s / PER, j = s % PER, k = j % 5;
-        // (border blocks: a tile none of whose right columns exists keeps its start values, nothing is fetched or multiplied for it)
-        if (!EDGE || t >= st.dead) {
-            const mx_v8i b = mx_frag(fb[s % P]);
-            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(j >= 5 ? ao[k] : an[k], b, acc[t], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        }
+        const mx_v8i b = mx_frag(fb[s % P]);
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(j >= 5 ? ao[k] : an[k], b, acc[t], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         asm volatile("" : "+v"(acc[t]));      // keeps the instruction at this place among the ordered statements around it
         if constexpr (s == MEET) mx_meet();
-        if (!EDGE || ((s + P) % S) / PER >= st.dead) fb[s % P] = right(s + P);
+        fb[s % P] = right(s + P);
         if constexpr (s >= MEET && s < MEET + 5) an[s - MEET] = mx_frag(nxt_e[G::RPX + (s - MEET)]);   // its last use was this instruction
 
         // this thread's share of the next staged rows
@@ -402,8 +398,6 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     }
     auto word = [&](int i, int r) -> uint32_t { return st.src[i][r * row_words]; };   // word of staging round i in census row r of the strip
     st.slot0 = (tid & 1) * G::PLANE + (tid >> 1);
-    // tile t holds right columns r0 + 32 t .. r0 + 32 t + 31; no view admits a right column below 2
-    st.dead = EDGE ? min(max((2 - 31 - r0 + 31) / 32, 0), T - 1) : 0;
     st.tail_wave = (G::ROUNDS - 1) * (64 * MX_W) + wave * 64 < G::WORDS;
     st.tail_lane = (G::ROUNDS - 1) * (64 * MX_W) + tid < G::WORDS;
     const int last = n_rows - 1;
@@ -485,9 +479,9 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     const int n_rows = y_hi - y_lo + 4;              // census rows y_lo-2 .. y_hi+1
     const long part_stride = (long)n_xblocks * (32 * T);
     float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)bx * (32 * T) : nullptr;
-    // blocks in which the two views admit different pairs, or whose first tiles lie left of the frame
-    const bool edge = (BOTH && (xl0 - 32 * (T - 1) < 5 || xl0 + MX_M - 1 > cols - 6)) || xl0 - 32 * (T - 1) + 31 < 2;
-    if (edge) mx_strip<T, BOTH, true>(lds, cl, cr, cols, max_disp, xl0, xl0_wg, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    // blocks in which the two views admit different pairs
+    const bool edge = BOTH && (xl0 - 32 * (T - 1) < 5 || xl0 + MX_M - 1 > cols - 6);
+    if (edge) mx_strip<T, BOTH, BOTH>(lds, cl, cr, cols, max_disp, xl0, xl0_wg, y_lo, n_rows, tid, disp, part_row0, part_stride);
     else mx_strip<T, BOTH, false>(lds, cl, cr, cols, max_disp, xl0, xl0_wg, y_lo, n_rows, tid, disp, part_row0, part_stride);
 
     if (write_border) {
