@@ -286,7 +286,7 @@ def main():
         kernel_name = S.dense_kernel_name(rows, cols, words, D, both_views, ctx) if variant != "5x5" else S.DOMINANT_KERNEL
         on_matrix_cores = kernel_name == "dense_wta_mx_kernel"
         if on_matrix_cores:      # 32 keys per tile of right columns, output row and 32-column block
-            part_bytes = 4.0 * 32 * (3 if D <= 64 else 5 if D <= 128 else 9) * F * (rows - 4) * ((cols - 4 + 31) // 32) if both_views else 0.0
+            part_bytes = 4.0 * 32 * (3 if D <= 64 else 5) * max(1, -(-D // 128)) * F * (rows - 4) * ((cols - 4 + 31) // 32) if both_views else 0.0
         else:
             part_bytes = 4.0 * 80 * F * (rows - 4) * ((cols - 4 + 15) // 16) * ((D + 63) // 64) if both_views else 0.0
         kernel_io_bytes = float(rows * cols * F * (2 * 4 * words + 4)) + part_bytes     # what this kernel itself must move
@@ -334,15 +334,15 @@ def main():
             # algorithmic work = per pix*disp one 5-column x 64-bit dot product for the census row that enters the 5-row
             # window and one for the row that leaves it = 2 * 5 * 64 multiply-adds = 1280 flop.  The vector-popcount
             # pricing used for the sweep kernel (2 lane-instructions per descriptor word and pix*disp) stays beside it.
-            tiles = 3 if D <= 64 else 5 if D <= 128 else 9
+            tiles, passes = (3 if D <= 64 else 5), max(1, -(-D // 128))       # more than 128 disparities: passes of 128 (five tiles each)
             # strips as svx_launch_mx_sweep chooses them (a strip's first five rows have nothing leaving the window yet)
-            slots = torch.cuda.get_device_properties(dev).multi_processor_count * (8 if tiles <= 5 else 4)
-            per_strip = ((cols - 4 + 31) // 32) * F
+            slots = torch.cuda.get_device_properties(dev).multi_processor_count * 2     # workgroups of four wavefronts, two per CU
+            per_strip = -(-((cols - 4 + 31) // 32) // 4) * F
             cost = lambda k: -(-per_strip * k // slots) * (-(-(rows - 4) // k) + 6)
             k_best = min(range(1, min(16, rows - 4) + 1), key=lambda k: (cost(k), k))
             strip_rows = -(-(rows - 4) // k_best)
             strips = -(-(rows - 4) // strip_rows)
-            mfma_count = tiles * (10 * (rows - 4 + 4 * strips) - 25 * strips) * ((cols - 4 + 31) // 32) * F
+            mfma_count = passes * tiles * (10 * (rows - 4 + 4 * strips) - 25 * strips) * ((cols - 4 + 31) // 32) * F
             issued_flops = 2.0 * 32 * 32 * 64 * mfma_count
             alg_flops = 1280.0 * pixdisp_per_frame * F
             # The headline stays the vector-popcount floor (one xor + one popcount per descriptor word and pix*disp), the

@@ -68,12 +68,14 @@ int svx_synchronize(svx_ctx *ctx);
  *   SVX_OPT_MX_STRIP_ROWS    (SVX_MX_STRIP_ROWS)   > 0 forces the output rows per strip of the matrix-core search
  *   SVX_OPT_STAGE_TIMES      (SVX_STAGE_TIMES)     1 = svx_high_perf_stereo synchronises at its stage marks and fills
  *                                                  svx_pipeline_stage_times (default 0: no synchronisation, times 0)
+ *   SVX_OPT_MX_WIDE_TILES    (SVX_MX_WIDE_TILES)   1 = 129..256 disparities in one pass of the nine-tile matrix-core kernel
+ *                                                  instead of two passes of the five-tile one (default 0)
  * The one option that changes results:
  *   SVX_OPT_PRIOR_BAND_RADIUS (SVX_PRIOR_BAND_RADIUS) radius of svx_high_perf_stereo's search around the plane prior
  *                                                  (svx_cost_eval_band); default 0 = the reference's single disparity */
 enum svx_option {
     SVX_OPT_MATRIX_CORES = 0, SVX_OPT_LR_TWO_SWEEPS = 1, SVX_OPT_SWEEP_WAVES = 2, SVX_OPT_SWEEP_WAVES_BOTH = 3,
-    SVX_OPT_CENSUS97_PACKED = 4, SVX_OPT_MX_STRIP_ROWS = 5, SVX_OPT_STAGE_TIMES = 6, SVX_OPT_PRIOR_BAND_RADIUS = 7, SVX_OPT_COUNT = 8
+    SVX_OPT_CENSUS97_PACKED = 4, SVX_OPT_MX_STRIP_ROWS = 5, SVX_OPT_STAGE_TIMES = 6, SVX_OPT_PRIOR_BAND_RADIUS = 7, SVX_OPT_MX_WIDE_TILES = 8, SVX_OPT_COUNT = 9
 };
 int svx_set_option(svx_ctx *ctx, int option, int value);
 int svx_get_option(const svx_ctx *ctx, int option, int *value);   /* ctx NULL: the default a new context would get */
@@ -485,12 +487,13 @@ int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left, const 
 /* Which kernel the dense search of this size runs in this context (for benchmarks that name the kernel they time):
  * 0 = the vector sweep, 1 = the matrix-core search, 2 = one thread per pixel.  both_views: the search of
  * svx_dense_wta_both and of the fused left-right entry points.  Follows SVX_OPT_MATRIX_CORES; the default uses the
- * matrix cores for the both-views search on two-word descriptors at up to 256 disparities.  ctx NULL: the choice of a
+ * matrix cores for the both-views search on two-word descriptors at up to 1024 disparities.  ctx NULL: the choice of a
  * new context.  No counterpart in the reference.  Host only. */
 int svx_dense_kernel_choice(const svx_ctx *ctx, int rows, int cols, int words, int max_disp, int both_views);
 /* The search of svx_dense_wta / svx_dense_wta_both on two-word descriptors with the cost values formed on the matrix
  * cores (fp4 dot products of the expanded descriptors; denseCensusStereo/denseCensusStereo.cpp:87-131 generalised as
- * there): identical results.  Covers cols >= 36, rows >= 5, 1 <= max_disp <= 256 (SVX_ERR_UNSUPPORTED otherwise).
+ * there): identical results.  Covers cols >= 36, rows >= 5, 1 <= max_disp <= 1024 (SVX_ERR_UNSUPPORTED otherwise); more
+ * than 128 disparities are searched in passes of 128 whose winners' keys are merged.
  * disp_right may be NULL (left view only).  Border pixels are written as 0.  Asynchronous. */
 int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
                          int max_disp, float *disp_left, float *disp_right);

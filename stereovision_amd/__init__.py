@@ -27,6 +27,7 @@ from ._lib import (  # noqa: F401
     OPT_MX_STRIP_ROWS,
     OPT_STAGE_TIMES,
     OPT_PRIOR_BAND_RADIUS,
+    OPT_MX_WIDE_TILES,
     EXPORTS,
     DOMINANT_KERNEL,
     dense_kernel_name,

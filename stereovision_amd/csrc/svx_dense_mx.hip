@@ -33,7 +33,7 @@ typedef float mx_v16f __attribute__((ext_vector_type(16)));
 #endif              // row's instruction s always finds its operand in slot s % MX_P, also when the previous row fetched it
 constexpr int MX_M = 32;                 // left columns per wavefront
 #ifndef MX_MAX_DISP
-#define MX_MAX_DISP 256   // 3, 5 or 9 tiles of 32 right columns (17 tiles for 512 disparities spill: 27.5 against 13.3 ms at 4K)
+#define MX_MAX_DISP 1024  // the disparity tag in the keys has ten bits; wider ranges than one launch covers run in passes (mx_plan)
 #endif
 
 #ifndef MX_W
@@ -125,6 +125,7 @@ struct MxState {
     const uint32_t *src[G::ROUNDS];                          // this thread's word of staging round i in census row 0 of the strip
     uint32_t flip[G::ROUNDS];                                // all ones where that word is a left word
     int slot0;                                               // where this thread's word of round 0 goes in a staged row (round i: + 32 MX_W i)
+    bool own;                                                // this lane's left column belongs to this x-block alone (the last block is shifted over its neighbour)
     bool tail_wave, tail_lane;                               // last, partial round: this wavefront takes part / this lane holds a word
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
     float pen_l[T], pen_r[16];                               // border blocks: what each view must not use (0 or -2^21)
@@ -171,8 +172,11 @@ __device__ __forceinline__ float mx_decode(float z) {
     return z < -524288.0f ? 0.0f : 1023.0f - frac * 1024.0f;
 }
 
+// pass_flags: what a search over part of the disparity range does with the left map.  Bit 0: an earlier pass over smaller
+// disparities left its winner's key in the map, which competes (keys carry their disparity: the larger key is the better
+// pair, the smaller disparity among equal costs); bit 1: a later pass follows, so the key itself is stored, not decoded.
 template <int T>
-__device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane) {
+__device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane, int pass_flags) {
     const float w0 = (lane & 1) ? st.rc[1] : st.rc[0];
     const float w1 = (lane & 1) ? st.rc[3] : st.rc[2];
     float x0, x1;
@@ -182,7 +186,11 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane) {
                  : "=&v"(x0), "=&v"(x1) : "v"(w0), "v"(w1));
     float z = (lane & 2) ? x1 : x0;                          // lane l: register (l & 15) over its 16-lane row
     const float zo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, z), 0x401f));   // lane ^ 16
-    *st.out = mx_decode(mx_max(z, zo));                      // lanes l and l ^ 16 write the same value to the same place
+    z = mx_max(z, zo);
+    if (st.own) {                                            // (a column that two x-blocks cover is written by one of them: with passes the map is read back)
+        if (pass_flags & 1) z = mx_max(z, *st.out);
+        *st.out = (pass_flags & 2) ? z : mx_decode(z);       // lanes l and l ^ 16 write the same value to the same place
+    }
 }
 
 // One census row r of a strip.  Its operands are in the staged rows cur_e (row r, entering the 5-row window) and cur_l
@@ -198,7 +206,7 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane) {
 template <int T, bool STEADY, bool BOTH, bool EDGE>
 __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *cur_e, const uint4 *cur_l, const uint4 *nxt_e,
                                        uint4 *stage_e, uint4 *stage_l, MxState<T> &st, mx_v8i (&an)[5], uint4 (&fb)[MX_P],
-                                       long off_new, long off_old, int lane, int swap32) {
+                                       long off_new, long off_old, int lane, int swap32, int pass_flags) {
     using G = MxGeom<T>;
     constexpr int PER = STEADY ? 10 : 5, S = T * PER, P = MX_P;
     constexpr int MEET = mx_meet_step<T, STEADY>();
@@ -282,7 +290,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *cur_e, co
             if constexpr (t == 2 && j == 0) { MX_RED_B(0); MX_RED_B(1); }
             if constexpr (t == 2 && j == 1) { MX_RED_B(2); MX_RED_B(3); }
             if constexpr (t == 2 && j == 2) { MX_RED_C(); }
-            if constexpr (t == 2 && j == 3) { mx_reduce_tail<T>(st, lane); st.out += st.out_stride; }
+            if constexpr (t == 2 && j == 3) { mx_reduce_tail<T>(st, lane, pass_flags); st.out += st.out_stride; }
             // right view: tile t - 1 of this row, or the last tile of the previous row
             if constexpr (BOTH) {
                 constexpr int u = t == 0 ? T - 1 : t - 1;
@@ -321,7 +329,7 @@ __device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState
 
 // After the last row of a strip: its last tile, the lane reduction and the stores (nothing follows to hide them behind).
 template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<T> &st, int lane, int swap32) {
+__device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<T> &st, int lane, int swap32, int pass_flags) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (T == 5) st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, 3, i));
@@ -333,7 +341,7 @@ __device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<
     MX_RED_B(0); MX_RED_B(1); MX_RED_B(2); MX_RED_B(3);
     MX_DPP_GAP();
     MX_RED_C();
-    mx_reduce_tail<T>(st, lane);
+    mx_reduce_tail<T>(st, lane, pass_flags);
     if (BOTH) {
         float rx[5];
         mx_right_a<T, EDGE, T - 1>(acc, st, rx);
@@ -351,12 +359,12 @@ __device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<
 // behind the meeting point of row r (the next image) is complete.
 template <int T, bool BOTH, bool EDGE>
 __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
-                                         int cols, int max_disp, int xl0, int xl0_wg, int y_lo, int n_rows, int tid, float *__restrict__ disp,
-                                         float *__restrict__ part_row0, long part_stride) {
+                                         int cols, int max_disp, int d_base, int pass_flags, int xl0, int xl0_wg, int own_from, int y_lo, int n_rows, int tid,
+                                         float *__restrict__ disp, float *__restrict__ part_row0, long part_stride) {
     using G = MxGeom<T>;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
-    const int r0 = xl0 - 32 * (T - 1);               // right column of tile 0, lane 0
+    const int r0 = xl0 - 32 * (T - 1) - d_base;      // right column of tile 0, lane 0 (this pass searches disparities d_base .. d_base + 32 (T - 1) - 1)
     const int swap32 = (lane ^ 32) * 4;
 
     // Accumulator element i of tile t is (left column xl0 + m, right column r0 + 32 t + n).  It starts at
@@ -374,14 +382,14 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         for (int i = 0; i < 16; ++i) {
             const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
             const int d = xl0 + m - xr;
-            const bool ok = d >= 0 && d < max_disp && xr >= (BOTH ? 2 : 5);
+            const bool ok = d >= d_base && d < min(max_disp, d_base + 32 * (T - 1)) && xr >= (BOTH ? 2 : 5);
             acc[t][i] = ok ? (float)(1023 - d) * (1.0f / 1024.0f) : -1048576.0f;
         }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.pen_r[i] = xl0 + (i & 3) + 8 * (i >> 2) + 4 * h <= cols - 6 ? 0.0f : -2097152.0f;
 
-    // staging: word q of a staged row is right word (xl0_wg - 32 (T - 1) - 2) * 2 + q for q < 2 RPX, left word
+    // staging: word q of a staged row is right word (xl0_wg - 32 (T - 1) - d_base - 2) * 2 + q for q < 2 RPX, left word
     // (xl0_wg - 2) * 2 + q - 2 RPX after it; thread tid takes the words tid, tid + 256, ...  Words outside the frame
     // are clamped into it: left of the frame they only feed inadmissible pairs, right of it (the columns behind the
     // last x-block of a workgroup that the frame does not fill) nothing reads them.
@@ -391,7 +399,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     for (int i = 0; i < G::ROUNDS; ++i) {
         const int q = min(i * (64 * MX_W) + tid, G::WORDS - 1);
         const bool is_left = q >= 2 * G::RPX;
-        const long wr = min(max((long)(xl0_wg - 32 * (T - 1) - 2) * 2 + q, 0L), row_words - 1);
+        const long wr = min(max((long)(xl0_wg - 32 * (T - 1) - d_base - 2) * 2 + q, 0L), row_words - 1);
         const long wl = min(max((long)(xl0_wg - 2) * 2 + (q - 2 * G::RPX), 0L), row_words - 1);
         st.src[i] = is_left ? cl0 + wl : cr0 + wr;
         st.flip[i] = is_left ? 0xffffffffu : 0u;
@@ -403,6 +411,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     const int last = n_rows - 1;
     const int i_out = lane & 15;
     st.out = disp + (long)y_lo * cols + xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h;
+    st.own = xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h >= own_from;
     st.out_stride = cols;
     st.part = part_row0 + n;
     st.part_stride = part_stride;
@@ -436,7 +445,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
 #pragma unroll 1
     for (int r = 0; r < 5; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)max(r - 3, 0) * row_words;
-        mx_row<T, false, BOTH, EDGE>(acc, img_e(b_cur) + rd, img_l(b_cur) + rd, img_e(b_nxt) + rd, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32);
+        mx_row<T, false, BOTH, EDGE>(acc, img_e(b_cur) + rd, img_l(b_cur) + rd, img_e(b_nxt) + rd, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32, pass_flags);
         b_cur = b_nxt;
         b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
     }
@@ -444,22 +453,23 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
 #pragma unroll 1
     for (int r = 5; r < n_rows; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)(r - 3) * row_words;
-        mx_row<T, true, BOTH, EDGE>(acc, img_e(b_cur) + rd, img_l(b_cur) + rd, img_e(b_nxt) + rd, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32);
+        mx_row<T, true, BOTH, EDGE>(acc, img_e(b_cur) + rd, img_l(b_cur) + rd, img_e(b_nxt) + rd, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32, pass_flags);
         b_cur = b_nxt;
         b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
     }
-    mx_last_output<T, BOTH, EDGE>(acc, st, lane, swap32);
+    mx_last_output<T, BOTH, EDGE>(acc, st, lane, swap32, pass_flags);
 }
 
 // grid: (groups of MX_W x-blocks, strips, frames), MX_W wavefronts per block, one per x-block.  x-block b owns output
 // columns [xl0, xl0 + 32), xl0 = min(2 + 32 b, cols - 34) (the last block is shifted left to end at column cols-3);
 // a wavefront behind the last x-block repeats it (same results to the same places).
-// Requires cols >= 36, rows >= 5, max_disp <= 32 * (T - 1).
+// Searches disparities d_base .. min(max_disp, d_base + 32 (T - 1)) - 1; a wider range takes several launches (pass_flags:
+// mx_reduce_tail).  Requires cols >= 36, rows >= 5.
 // BOTH: also stores, for every output row and x-block, the right view's best key of each of the block's 32 T right
 // columns over the block's left columns: partial[frame][row][x-block][32 T] (svx_mx_right_disparity merges them).
 template <int T, bool BOTH>
 __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
-                                                          int rows, int cols, int max_disp, int strip_rows, int n_xblocks,
+                                                          int rows, int cols, int max_disp, int d_base, int pass_flags, int strip_rows, int n_xblocks,
                                                           float *__restrict__ disp_all, int write_border, float *__restrict__ partial) {
     using G = MxGeom<T>;
     __shared__ uint4 lds[MX_NBUF * 2 * G::SLOTS];    // [image][entering row, leaving row][see MxGeom]
@@ -473,16 +483,19 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     const uint32_t *cl = cl_all + bz * npx * 2;
     const uint32_t *cr = cr_all + bz * npx * 2;
     float *disp = disp_all + bz * npx;
-    const int bx = min((int)gx * MX_W + __builtin_amdgcn_readfirstlane(tid >> 6), n_xblocks - 1);
+    const int bx_wave = (int)gx * MX_W + __builtin_amdgcn_readfirstlane(tid >> 6), bx = min(bx_wave, n_xblocks - 1);
+    // left columns from own_from on are this wavefront's to write: the last x-block is shifted over its neighbour, and a
+    // wavefront behind the last x-block writes nothing to the left map
+    const int own_from = bx_wave > n_xblocks - 1 ? 0x7fffffff : 2 + bx * MX_M;
     const int xl0 = min(2 + bx * MX_M, cols - 2 - MX_M), xl0_wg = min(2 + (int)gx * MX_W * MX_M, cols - 2 - MX_M);
     const int y_lo = 2 + (int)by * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
     const int n_rows = y_hi - y_lo + 4;              // census rows y_lo-2 .. y_hi+1
     const long part_stride = (long)n_xblocks * (32 * T);
     float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)bx * (32 * T) : nullptr;
     // blocks in which the two views admit different pairs
-    const bool edge = BOTH && (xl0 - 32 * (T - 1) < 5 || xl0 + MX_M - 1 > cols - 6);
-    if (edge) mx_strip<T, BOTH, BOTH>(lds, cl, cr, cols, max_disp, xl0, xl0_wg, y_lo, n_rows, tid, disp, part_row0, part_stride);
-    else mx_strip<T, BOTH, false>(lds, cl, cr, cols, max_disp, xl0, xl0_wg, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    const bool edge = BOTH && (xl0 - 32 * (T - 1) - d_base < 5 || xl0 + MX_M - 1 > cols - 6);
+    if (edge) mx_strip<T, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    else mx_strip<T, BOTH, false>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
 
     if (write_border) {
         // rows outside [2, rows-2) over this block's columns, and the two border columns on either side
@@ -496,47 +509,56 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     }
 }
 
-// Right view from the partial keys: right pixel xr can match left columns xr .. xr + max_disp - 1, which lie in the
-// x-blocks whose first left column xl0 satisfies xr - 31 <= xl0 <= xr + 32 (T - 1); block b keeps xr in slot
-// xr - (xl0 - 32 (T - 1)).
+// Right view from the partial keys: right pixel xr can match left columns xr .. xr + max_disp - 1.  Within one pass
+// (disparities d_base .. d_base + 32 (T - 1) - 1) they lie in the x-blocks whose first left column xl0 satisfies
+// xs - 31 <= xl0 <= xs + 32 (T - 1) with xs = xr + d_base; block b keeps xr in slot xs - (xl0 - 32 (T - 1)).
+// Returns the best key of that pass.
 template <int T>
-__device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, int xr, int cols, int n_xblocks) {
+__device__ __forceinline__ float svx_mx_right_key(const float *__restrict__ prow, int xs, int cols, int n_xblocks) {
     float best = -1048576.0f;
-    const int b_first = max((xr - 31 - 2 + MX_M - 1) / MX_M, 0);       // smallest b with 2 + 32 b >= xr - 31
-    if (xr >= 2 && b_first + T - 1 < n_xblocks - 1) {
-        // all regular blocks (xl0 = 2 + 32 b): exactly T of them reach xr, block b_first + k in slot ((xr - 2) & 31) + 32 (T - 1 - k)
-        const float *p = prow + (long)b_first * (32 * T) + ((xr - 2) & 31) + 32 * (T - 1);
+    const int b_first = max((xs - 31 - 2 + MX_M - 1) / MX_M, 0);       // smallest b with 2 + 32 b >= xs - 31
+    if (xs >= 2 && b_first + T - 1 < n_xblocks - 1) {
+        // all regular blocks (xl0 = 2 + 32 b): exactly T of them reach xs, block b_first + k in slot ((xs - 2) & 31) + 32 (T - 1 - k)
+        const float *p = prow + (long)b_first * (32 * T) + ((xs - 2) & 31) + 32 * (T - 1);
 #pragma unroll
         for (int k = 0; k < T; ++k) best = fmaxf(best, p[k * (32 * T - 32)]);
-        return mx_decode(best);
+        return best;
     }
 #pragma unroll
     for (int k = 0; k < T + 1; ++k) {
         const int b = min(b_first + k, n_xblocks - 1);
         const int xl0 = min(2 + b * MX_M, cols - 2 - MX_M);
-        const int slot = xr - (xl0 - 32 * (T - 1));
+        const int slot = xs - (xl0 - 32 * (T - 1));
         const bool ok = slot >= 0 && slot < 32 * T;
         const float v = prow[(long)b * (32 * T) + min(max(slot, 0), 32 * T - 1)];
         best = fmaxf(best, ok ? v : -1048576.0f);
     }
+    return best;
+}
+
+// The right disparity of (xr, row) over all passes: pass p's keys lie pass_stride floats behind pass p - 1's.
+template <int T>
+__device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, long pass_stride, int n_pass, int xr, int cols, int n_xblocks) {
+    float best = svx_mx_right_key<T>(prow, xr, cols, n_xblocks);
+    for (int p = 1; p < n_pass; ++p) best = fmaxf(best, svx_mx_right_key<T>(prow + p * pass_stride, xr + p * 32 * (T - 1), cols, n_xblocks));
     return mx_decode(best);
 }
 
 template <int T>
-__global__ __launch_bounds__(256) void mx_right_view_merge_kernel(const float *__restrict__ partial, int rows, int cols, int n_xblocks,
-                                                                  float *__restrict__ disp_right_all) {
+__global__ __launch_bounds__(256) void mx_right_view_merge_kernel(const float *__restrict__ partial, long pass_stride, int n_pass, int rows, int cols,
+                                                                  int n_xblocks, float *__restrict__ disp_right_all) {
     const int xr = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (xr >= cols) return;
     float *out = disp_right_all + ((long)blockIdx.z * rows + y) * cols;
     if (xr < 2 || xr >= cols - 2 || y < 2 || y >= rows - 2) { out[xr] = 0.0f; return; }
     const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * 32 * T);
-    out[xr] = svx_mx_right_disparity<T>(prow, xr, cols, n_xblocks);
+    out[xr] = svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_xblocks);
 }
 
 // Left-right check straight from the partial keys (the rule of svx_lr_check with the right disparity merged on demand).
 template <int T>
-__global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl_all, const float *__restrict__ partial, int rows, int cols,
-                                                          int n_xblocks, float threshold, float invalid) {
+__global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl_all, const float *__restrict__ partial, long pass_stride, int n_pass,
+                                                          int rows, int cols, int n_xblocks, float threshold, float invalid) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
     float *dl = dl_all + ((long)blockIdx.z * rows + y) * cols;
@@ -545,23 +567,34 @@ __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl
     const int xr = x - (int)d1;
     if (xr < 2) { dl[x] = invalid; return; }
     const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * 32 * T);
-    if (fabsf(svx_mx_right_disparity<T>(prow, xr, cols, n_xblocks) - d1) > threshold) dl[x] = invalid;
+    if (fabsf(svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_xblocks) - d1) > threshold) dl[x] = invalid;
 }
 
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX_M + 4 && rows >= 5 && max_disp >= 1 && max_disp <= MX_MAX_DISP; }
 
-static int mx_tiles(int max_disp) { return max_disp <= 64 ? 3 : max_disp <= 128 ? 5 : 9; }
+// Tiles per wavefront and launches per search: up to 64 / 128 disparities three / five tiles in one pass; wider ranges in
+// passes of 128 disparities with five tiles (two wavefronts per SIMD; nine tiles in one pass leave room for one, which is
+// slower per disparity), unless SVX_OPT_MX_WIDE_TILES asks for the nine-tile kernel at up to 256.
+struct MxPlan { int tiles, passes; };
+static MxPlan mx_plan(const svx_ctx *ctx, int max_disp) {
+    if (max_disp <= 64) return {3, 1};
+    if (max_disp <= 128) return {5, 1};
+    if (max_disp <= 256 && svx_opt(ctx, SVX_OPT_MX_WIDE_TILES) == 1) return {9, 1};
+    return {5, (max_disp + 127) / 128};
+}
 static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }
 
-size_t svx_mx_partial_words(int rows, int cols, int n_frames, int max_disp) {
-    return (size_t)n_frames * rows * mx_xblocks(cols) * 32 * mx_tiles(max_disp);
+size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames, int max_disp) {
+    const MxPlan plan = mx_plan(ctx, max_disp);
+    return (size_t)plan.passes * n_frames * rows * mx_xblocks(cols) * 32 * plan.tiles;
 }
 
 // Left-view search on two-word descriptors; see svx_dense.hip for the meaning of the arguments.
 // partial != nullptr: also the right view's partial keys (svx_mx_partial_words floats).
 int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
                         float *disparity, int write_border, float *partial) {
-    const int T = mx_tiles(max_disp);
+    const MxPlan plan = mx_plan(ctx, max_disp);
+    const int T = plan.tiles;
     // Strips: every strip re-reads 4 halo rows and starts with 5 rows that fill the window, but the grid should fill the
     // chip a whole number of times (8 wavefronts or, with nine tiles, 4 fit a CU): take the
     // number of strips with the smallest (rounds of wavefronts) x (rows a wavefront walks).
@@ -583,13 +616,19 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     n_strips = (out_rows + strip_rows - 1) / strip_rows;
     const dim3 grid(n_groups, n_strips, n_frames), block(64 * MX_W);
     const int nb = mx_xblocks(cols);
-    if (T == 9 && !partial) dense_wta_mx_kernel<9, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, nullptr);
-    else if (T == 9) dense_wta_mx_kernel<9, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, partial);
-    else if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, nullptr);
-    else if (T == 3) dense_wta_mx_kernel<3, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, partial);
-    else if (!partial) dense_wta_mx_kernel<5, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, nullptr);
-    else dense_wta_mx_kernel<5, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, strip_rows, nb, disparity, write_border, partial);
-    SVX_LAUNCH_CHECK(ctx, "dense_wta_mx_kernel");
+    const size_t pass_words = (size_t)n_frames * rows * nb * 32 * T;
+    for (int p = 0; p < plan.passes; ++p) {
+        const int d_base = p * 32 * (T - 1), flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes ? 2 : 0);
+        const int wb = p + 1 == plan.passes ? write_border : 0;
+        float *part = partial ? partial + p * pass_words : nullptr;
+        if (T == 9 && !partial) dense_wta_mx_kernel<9, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, nullptr);
+        else if (T == 9) dense_wta_mx_kernel<9, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, part);
+        else if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, nullptr);
+        else if (T == 3) dense_wta_mx_kernel<3, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, part);
+        else if (!partial) dense_wta_mx_kernel<5, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, nullptr);
+        else dense_wta_mx_kernel<5, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, part);
+        SVX_LAUNCH_CHECK(ctx, "dense_wta_mx_kernel");
+    }
     return SVX_OK;
 }
 
@@ -599,21 +638,24 @@ int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, 
                         float *disp_left, float *disp_right, float lr_threshold) {
     const dim3 grid(svx_cdiv(cols, 256), rows, n_frames);
     const int nb = mx_xblocks(cols);
-    if (mx_tiles(max_disp) == 9) {
-        if (disp_right) mx_right_view_merge_kernel<9><<<grid, 256, 0, ctx->stream>>>(partial, rows, cols, nb, disp_right);
-        else mx_lr_check_kernel<9><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, rows, cols, nb, lr_threshold, -1.0f);
-    } else if (mx_tiles(max_disp) == 3) {
-        if (disp_right) mx_right_view_merge_kernel<3><<<grid, 256, 0, ctx->stream>>>(partial, rows, cols, nb, disp_right);
-        else mx_lr_check_kernel<3><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, rows, cols, nb, lr_threshold, -1.0f);
+    const MxPlan plan = mx_plan(ctx, max_disp);
+    const long ps = (long)n_frames * rows * nb * 32 * plan.tiles;
+    const int np = plan.passes;
+    if (plan.tiles == 9) {
+        if (disp_right) mx_right_view_merge_kernel<9><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
+        else mx_lr_check_kernel<9><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
+    } else if (plan.tiles == 3) {
+        if (disp_right) mx_right_view_merge_kernel<3><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
+        else mx_lr_check_kernel<3><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
     } else {
-        if (disp_right) mx_right_view_merge_kernel<5><<<grid, 256, 0, ctx->stream>>>(partial, rows, cols, nb, disp_right);
-        else mx_lr_check_kernel<5><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, rows, cols, nb, lr_threshold, -1.0f);
+        if (disp_right) mx_right_view_merge_kernel<5><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
+        else mx_lr_check_kernel<5><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
     }
     SVX_LAUNCH_CHECK(ctx, "mx right view kernel");
     return SVX_OK;
 }
 
-// The matrix-core form of svx_dense_wta_both on two-word descriptors (max_disp <= 256, cols >= 36, rows >= 5), run
+// The matrix-core form of svx_dense_wta_both on two-word descriptors (max_disp <= 1024, cols >= 36, rows >= 5), run
 // whatever the library's default choice of kernel is: left map, and with disp_right != NULL the right map from the
 // same accumulators.  Same results as svx_dense_wta / svx_dense_wta_both.
 SVX_API int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
@@ -623,9 +665,9 @@ SVX_API int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, cons
     SVX_REQUIRE(ctx, census_left && census_right && disp_left, SVX_ERR_INVALID_ARG, "svx_dense_wta_matrix: null pointer");
     SVX_REQUIRE(ctx, n_frames >= 1 && n_frames <= 65535 && rows <= 65535, SVX_ERR_INVALID_ARG, "svx_dense_wta_matrix: bad frame count or size");
     SVX_REQUIRE(ctx, svx_mx_sweep_eligible(rows, cols, max_disp), SVX_ERR_UNSUPPORTED,
-                "svx_dense_wta_matrix: needs cols >= 36, rows >= 5, 1 <= max_disp <= 256");
+                "svx_dense_wta_matrix: needs cols >= 36, rows >= 5, 1 <= max_disp <= 1024");
     if (!disp_right) return svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, nullptr);
-    const size_t per_frame = svx_mx_partial_words(rows, cols, 1, max_disp);
+    const size_t per_frame = svx_mx_partial_words(ctx, rows, cols, 1, max_disp);
     SVX_REQUIRE(ctx, per_frame * n_frames * sizeof(float) <= ((size_t)4 << 30), SVX_ERR_UNSUPPORTED, "svx_dense_wta_matrix: batch too large for one call");
     void *ws;
     rc = svx_ws_reserve(ctx, per_frame * n_frames * sizeof(float), &ws);

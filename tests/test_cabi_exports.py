@@ -47,7 +47,8 @@ def test_dense_kernel_choice_is_a_host_side_query():
     lib = S.load_library()
     assert lib.svx_dense_kernel_choice(None, 368, 1232, 2, 128, 1) == 1      # both views, two-word descriptors: matrix cores
     assert lib.svx_dense_kernel_choice(None, 1072, 1920, 2, 256, 1) == 1
-    assert lib.svx_dense_kernel_choice(None, 2160, 3840, 2, 512, 1) == 0     # more than 256 disparities: vector sweep
+    assert lib.svx_dense_kernel_choice(None, 2160, 3840, 2, 512, 1) == 1     # more than 128 disparities: passes of 128
+    assert lib.svx_dense_kernel_choice(None, 2160, 3840, 2, 1025, 1) == 2    # beyond what the keys' disparity tag holds
     assert lib.svx_dense_kernel_choice(None, 368, 1232, 1, 128, 1) == 0      # one-word descriptors
     assert lib.svx_dense_kernel_choice(None, 368, 1232, 2, 128, 0) == 0      # single view
     assert lib.svx_dense_kernel_choice(None, 4, 1232, 2, 128, 0) == 2

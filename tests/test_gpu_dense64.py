@@ -74,7 +74,8 @@ def test_dense_wta_both_views_from_one_sweep(ctx, rows, cols, max_disp, words):
 
 
 @pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (12, 40, 64), (30, 150, 128), (5, 36, 1), (110, 90, 70), (9, 300, 100),
-                                                 (101, 37, 33), (7, 200, 128), (40, 133, 65), (20, 300, 200), (12, 400, 256), (9, 290, 129)])
+                                                 (101, 37, 33), (7, 200, 128), (40, 133, 65), (20, 300, 200), (12, 400, 256), (9, 290, 129),
+                                                 (8, 700, 512), (6, 600, 300), (7, 1300, 1024)])
 def test_dense_wta_matrix_matches_oracle(ctx, rows, cols, max_disp):
     """The matrix-core form: both views bit for bit, on descriptors with few distinct values (many cost ties)."""
     rng = np.random.default_rng(rows * 1000 + cols + max_disp)
@@ -91,7 +92,7 @@ def test_dense_wta_matrix_matches_oracle(ctx, rows, cols, max_disp):
         assert np.array_equal(dr[f], want_r), (f, np.argwhere(dr[f] != want_r)[:5])
 
 
-@pytest.mark.parametrize("rows,cols,max_disp", [(40, 420, 64), (23, 300, 128), (30, 330, 256)])
+@pytest.mark.parametrize("rows,cols,max_disp", [(40, 420, 64), (23, 300, 128), (30, 330, 256), (12, 900, 400)])
 def test_dense_wta_matrix_close_costs(ctx, rows, cols, max_disp):
     """Descriptors of real image texture: neighbouring disparities cost almost the same, so one wrong operand anywhere in
     a window moves the winner (random descriptors with one planted match would not notice)."""
@@ -111,7 +112,7 @@ def test_dense_wta_matrix_refuses_what_it_does_not_cover(ctx):
         ctx.dense_wta_matrix(cl, cl, 16)
     cl = dev_u32(np.zeros((1, 8, 64, 2), np.uint32))
     with pytest.raises(S.SvxError):
-        ctx.dense_wta_matrix(cl, cl, 257)
+        ctx.dense_wta_matrix(cl, cl, 1025)
 
 
 def test_left_view_one_word_is_the_reference_search(ctx):
@@ -158,7 +159,7 @@ def test_lr_check_values_that_are_no_disparity(ctx):
 
 
 @pytest.mark.parametrize("rows,cols,D,frames", [(375, 1242, 64, 2), (368, 1232, 128, 2), (1072, 1920, 200, 1), (540, 960, 256, 1),
-                                                 (300, 2000, 33, 1), (300, 2000, 65, 1), (300, 2000, 129, 1)])
+                                                 (300, 2000, 33, 1), (300, 2000, 65, 1), (300, 2000, 129, 1), (270, 1920, 512, 1), (200, 1600, 300, 2)])
 def test_matrix_search_equals_vector_sweep_on_whole_frames(ctx, rows, cols, D, frames):
     """Every tile count of the matrix-core search (3, 5 and 9 tiles: up to 64, 128 and 256 disparities), both views, on
     whole large frames against the vector sweep (itself checked against the oracle on bands of such frames): a build of
@@ -175,6 +176,13 @@ def test_matrix_search_equals_vector_sweep_on_whole_frames(ctx, rows, cols, D, f
         ctx.set_option(S.OPT_MATRIX_CORES, -1)
     ml, mr = ctx.dense_wta_matrix(cl, cr, D)
     ml0, _ = ctx.dense_wta_matrix(cl, cr, D, both=False)
+    if 128 < D <= 256:                      # the one-pass nine-tile kernel beside the two passes of five tiles
+        ctx.set_option(S.OPT_MX_WIDE_TILES, 1)
+        try:
+            nl, nr = ctx.dense_wta_matrix(cl, cr, D)
+        finally:
+            ctx.set_option(S.OPT_MX_WIDE_TILES, 0)
+        assert torch.equal(nl, wl) and torch.equal(nr, wr)
     assert torch.equal(ml, wl), (ml != wl).nonzero()[:5].tolist()
     assert torch.equal(ml0, wl), (ml0 != wl).nonzero()[:5].tolist()
     assert torch.equal(mr, wr), (mr != wr).nonzero()[:5].tolist()
