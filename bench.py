@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--lr-threshold", type=float, default=1.0)
     ap.add_argument("--size", default=None, help="WxH: run frames of exactly this size instead of the default workload "
                                                  "(1242x375 = the uncropped frame, borders as zeros; 1920x1072 and 3840x2160 = the larger configurations)")
+    ap.add_argument("--matrix-cores", type=int, choices=[-1, 0, 1], default=None,
+                    help="SVX_OPT_MATRIX_CORES of the context: 0 = vector sweep everywhere, 1 = matrix-core search wherever it applies (default: the library's choice)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend; gloo with --one-device rehearses the multi-rank path on a one-GPU box")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -210,6 +212,8 @@ def main():
     if args.size:
         cols, rows = (int(v) for v in args.size.lower().split("x"))
     ctx = S.Context(local_rank)
+    if args.matrix_cores is not None:
+        ctx.set_option(S.OPT_MATRIX_CORES, args.matrix_cores)
 
     # synthetic batch of this rank: F distinct pairs, seeds = global frame indices rank*F .. rank*F+F-1; staged to this
     # rank's GPU here (H2D per rank), resident in HBM before the timed region starts
@@ -283,7 +287,7 @@ def main():
         valu_ops = 2.0 * words * pixdisp_per_frame * F              # v_xor + v_bcnt per descriptor word per pix*disp
         # the dominant kernel's own traffic: both census batches in (4 B per word), the disparity map out, and for the
         # both-views sweep the right view's partial minima (80 words per output row, 16-column block and 64-disparity chunk)
-        kernel_name = S.dense_kernel_name(rows, cols, words, D, both_views, ctx) if variant != "5x5" else S.DOMINANT_KERNEL
+        kernel_name = S.dense_kernel_name(rows, cols, words, D, both_views, ctx)
         on_matrix_cores = kernel_name == "dense_wta_mx_kernel"
         if on_matrix_cores:      # 32 keys per tile of right columns, output row and 32-column block
             part_bytes = 4.0 * 32 * (3 if D <= 64 else 5) * max(1, -(-D // 128)) * F * (rows - 4) * ((cols - 4 + 31) // 32) if both_views else 0.0

@@ -59,8 +59,8 @@ int svx_synchronize(svx_ctx *ctx);
 /* Per-context options (no counterpart in the reference).  Except for the last one results never depend on them, only
  * the choice of kernel.  A new context starts from the built-in defaults, or from the environment variable named below when it is
  * set at svx_create time; svx_set_option overrides it for that context only.
- *   SVX_OPT_MATRIX_CORES     (SVX_MX)              -1 = matrix-core search where it is the faster kernel (default),
- *                                                  0 = never, 1 = wherever it applies
+ *   SVX_OPT_MATRIX_CORES     (SVX_MX)              0 = the vector sweep everywhere; any other value (default -1) = the
+ *                                                  matrix-core search wherever it applies
  *   SVX_OPT_LR_TWO_SWEEPS    (SVX_LR_TWO_SWEEPS)   1 = the left-right entry points search each view with its own sweep
  *   SVX_OPT_SWEEP_WAVES      (SVX_SWEEP_OCC)       2 or 3 wavefronts per SIMD for the vector sweep (default 3)
  *   SVX_OPT_SWEEP_WAVES_BOTH (SVX_SWEEP_OCC_BOTH)  the same for the both-views vector sweep
@@ -487,8 +487,8 @@ int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left, const 
 /* Which kernel the dense search of this size runs in this context (for benchmarks that name the kernel they time):
  * 0 = the vector sweep, 1 = the matrix-core search, 2 = one thread per pixel.  both_views: the search of
  * svx_dense_wta_both and of the fused left-right entry points.  Follows SVX_OPT_MATRIX_CORES; the default uses the
- * matrix cores for the both-views search on two-word descriptors at up to 1024 disparities.  ctx NULL: the choice of a
- * new context.  No counterpart in the reference.  Host only. */
+ * matrix cores for the left-view and the both-views search (one- or two-word descriptors, at least 36 columns and 5
+ * rows, up to 1024 disparities).  ctx NULL: the choice of a new context.  No counterpart in the reference.  Host only. */
 int svx_dense_kernel_choice(const svx_ctx *ctx, int rows, int cols, int words, int max_disp, int both_views);
 /* The search of svx_dense_wta / svx_dense_wta_both on two-word descriptors with the cost values formed on the matrix
  * cores (fp4 dot products of the expanded descriptors; denseCensusStereo/denseCensusStereo.cpp:87-131 generalised as

@@ -41,22 +41,24 @@ constexpr int MX_M = 32;                 // left columns per wavefront
 #endif
 constexpr int MX_NBUF = 3;               // staged rows in flight: the one being read, the one being written, and one in between (see mx_strip)
 
-template <int T>
+template <int T, int WORDS = 2>
 struct MxGeom {
     static constexpr int RPX = 32 * (MX_W + T - 1) + 4;   // right pixels staged per row for the workgroup (2-column window halo each side)
     static constexpr int LPX = 32 * MX_W + 4;
     static constexpr int PX = RPX + LPX;
-    static constexpr int WORDS = 2 * PX;                   // census words per staged row
-    static constexpr int ROUNDS = (WORDS + 64 * MX_W - 1) / (64 * MX_W);   // words per thread and row
-    static constexpr int FULL_ROUNDS = WORDS / (64 * MX_W);                // rounds in which every wavefront takes part
-    // LDS image of a staged row: one plane per descriptor word (= per k-half of the matrix instruction), a pixel's
-    // 32 fp4 values (16 bytes) at [word][pixel], right pixels first.  A 16-lane group of a 16-byte read then covers
-    // 256 consecutive bytes (with the two words of a pixel side by side it would hit every bank twice).  A write
-    // group of 8 lanes stores 4 pixels of each plane; the planes are PLANE pixels apart, PLANE = 4 mod 8, so that the two
-    // runs of 64 bytes land in different halves of the 32 banks a store sees.
-    static constexpr int PLANE = PX + (12 - PX % 8) % 8 + MX_PLANE_PAD;
-    static constexpr int SLOTS = 2 * PLANE;
-    static_assert(MX_PLANE_PAD != 0 || PLANE % 8 == 4, "plane offset must alternate the bank halves of a store");
+    static constexpr int NWORDS = WORDS * PX;              // census words per staged row
+    static constexpr int ROUNDS = (NWORDS + 64 * MX_W - 1) / (64 * MX_W);   // words per thread and row
+    static constexpr int FULL_ROUNDS = NWORDS / (64 * MX_W);                // rounds in which every wavefront takes part
+    static constexpr int ROUND_PX = 64 * MX_W / WORDS;     // pixels a round covers
+    // LDS image of a staged row, two-word descriptors: one plane per descriptor word (= per k-half of the matrix
+    // instruction), a pixel's 32 fp4 values (16 bytes) at [word][pixel], right pixels first.  A 16-lane group of a
+    // 16-byte read then covers 256 consecutive bytes (with the two words of a pixel side by side it would hit every
+    // bank twice).  A write group of 8 lanes stores 4 pixels of each plane; the planes are PLANE pixels apart,
+    // PLANE = 4 mod 8, so that the two runs of 64 bytes land in different halves of the 32 banks a store sees.
+    // One-word descriptors: a single plane (the two k-halves of an instruction are two different pixels, see mx_row).
+    static constexpr int PLANE = WORDS == 2 ? PX + (12 - PX % 8) % 8 + MX_PLANE_PAD : PX;
+    static constexpr int SLOTS = WORDS * PLANE;
+    static_assert(WORDS == 1 || MX_PLANE_PAD != 0 || PLANE % 8 == 4, "plane offset must alternate the bank halves of a store");
 };
 
 // 32 descriptor bits -> 32 fp4 values: dword j holds bits j, j+4, .. j+28 (the same permutation on both operands).
@@ -106,25 +108,31 @@ __device__ __forceinline__ float mx_max3(float a, float b, float c) { float r; a
 template <int... Is, class F>
 __device__ __forceinline__ void mx_static_for(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
 
-// Matrix instruction of a row after which the workgroup meets: the first one of the last tile.  From then on the row
-// only needs operands it has fetched already or fetches from its own staged row, and the next row's image, which
-// every wavefront has finished writing by then, may be read.
-template <int T, bool STEADY>
-constexpr int mx_meet_step() { return (STEADY ? 10 : 5) * (T - 1); }
+// Matrix instruction of a row after which the workgroup meets: the first one of the last tile (PER instructions per
+// tile).  From then on the row only needs operands it has fetched already or fetches from its own staged row, and the
+// next row's image, which every wavefront has finished writing by then, may be read.
+template <int T, int PER>
+constexpr int mx_meet_step() { return PER * (T - 1); }
 // Matrix instruction after which staging unit v (a round of the entering row, then the rounds of the leaving row) is
 // issued: spread over the instructions before the meeting, early enough that the operand wait of the instruction the
 // workgroup meets behind covers the unit's LDS write (LDS operations of a wavefront complete in order, and that
 // instruction's operand was fetched MX_P instructions ahead).
-template <int T, bool STEADY>
-constexpr int mx_unit_step(int v) { return 1 + v * (mx_meet_step<T, STEADY>() - MX_P - 1) / (2 * MxGeom<T>::ROUNDS); }
+template <int T, int WORDS, int PER>
+constexpr int mx_unit_step(int v) { return 1 + v * (mx_meet_step<T, PER>() - MX_P - 1) / (2 * MxGeom<T, WORDS>::ROUNDS); }
+
+// Where the operands of a row are: two-word descriptors read the entering and the leaving image at this lane's pixel;
+// with one-word descriptors each of the five instructions of a tile has a read position of its own (cur[j], nxt[j]).
+template <int WORDS> struct MxPtrs;
+template <> struct MxPtrs<2> { const uint4 *cur_e, *cur_l, *nxt_e; };
+template <> struct MxPtrs<1> { const uint4 *cur[5], *nxt[5]; };
 
 template <int T>
 struct MxState {
-    using G = MxGeom<T>;
+    using G = MxGeom<T, 2>;                                  // (sized for two-word descriptors; one-word ones use fewer rounds)
     uint32_t wn[G::ROUNDS], wo[G::ROUNDS];                   // census words of the next row to stage (entering, leaving)
     const uint32_t *src[G::ROUNDS];                          // this thread's word of staging round i in census row 0 of the strip
     uint32_t flip[G::ROUNDS];                                // all ones where that word is a left word
-    int slot0;                                               // where this thread's word of round 0 goes in a staged row (round i: + 32 MX_W i)
+    int slot0;                                               // where this thread's word of round 0 goes in a staged row (round i: + ROUND_PX i)
     bool own;                                                // this lane's left column belongs to this x-block alone (the last block is shifted over its neighbour)
     bool tail_wave, tail_lane;                               // last, partial round: this wavefront takes part / this lane holds a word
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
@@ -193,54 +201,72 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane, int pas
     }
 }
 
-// One census row r of a strip.  Its operands are in the staged rows cur_e (row r, entering the 5-row window) and cur_l
-// (row r-5, leaving it, left pixels negated); the pointers include this lane's pixel offset.  The first MX_P right
-// operands and the entering row's left operands (an) were fetched while the previous row ran.  Between its matrix
+// One census row r of a strip.  Its operands are in the workgroup's staged image of row r (entering the 5-row window)
+// and of row r-5 (leaving it, left pixels negated); the pointers of `ptr` include this lane's pixel offset.  The first
+// MX_P right operands and the left operands (an) were fetched while the previous row ran.  Between its matrix
 // instructions the wavefront expands its share of rows r+1 and r-4 into the workgroup's next staged rows (stage_e,
 // stage_l), fetches the words of rows r+2 and r-3 and, in the steady state (STEADY: the row five rows up leaves the
 // window, its products with the left operand negated are added too, and every row has an output), picks the winners:
 // a tile's accumulators are final from its last product until its first product of the next row, so tiles 0 .. T-2 are
 // read while later tiles of the same row run and tile T-1 while tile 0 of the next row runs, followed by the lane
 // reduction and the store of that previous row.  After the first product of the last tile the workgroup meets; behind
-// that point the next row's left operands and first right operands are fetched from nxt_e.
-template <int T, bool STEADY, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *cur_e, const uint4 *cur_l, const uint4 *nxt_e,
-                                       uint4 *stage_e, uint4 *stage_l, MxState<T> &st, mx_v8i (&an)[5], uint4 (&fb)[MX_P],
-                                       long off_new, long off_old, int lane, int swap32, int pass_flags) {
-    using G = MxGeom<T>;
-    constexpr int PER = STEADY ? 10 : 5, S = T * PER, P = MX_P;
-    constexpr int MEET = mx_meet_step<T, STEADY>();
+// that point the next row's left operands and first right operands are fetched from the next image.
+//
+// Two-word descriptors: an instruction's k = 64 is one pixel (its two words are the k-halves); a tile takes the five
+// window columns of the entering row and, in the steady state, the five of the leaving row (PER = 10).
+// One-word descriptors: k = 64 is TWO pixels, one per k-half (lanes 0..31 supply one, lanes 32..63 the other), so the
+// ten window pixels of the entering and the leaving row make five instructions, (e0,e1) (e2,e3) (e4,l0) (l1,l2) (l3,l4),
+// each with its own per-lane read position.  Before the steady state the leaving pixels are not there yet: the fourth
+// and fifth instruction are skipped and the third multiplies its second half by zero.
+template <int T, int WORDS, bool STEADY, bool BOTH, bool EDGE>
+__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &ptr, uint4 *stage_e, uint4 *stage_l, MxState<T> &st,
+                                       mx_v8i (&an)[5], uint4 (&fb)[MX_P], long off_new, long off_old, int lane, int swap32, int pass_flags) {
+    using G = MxGeom<T, WORDS>;
+    constexpr int PER = WORDS == 2 && STEADY ? 10 : 5, S = T * PER, P = MX_P;
+    constexpr int MEET = mx_meet_step<T, PER>();
     static_assert(S % P == 0 && S - P >= MEET && MEET - P - 1 >= 1, "operands of the next row are fetched behind the meeting point only, into the slots the row expects");
     static_assert(T >= 3, "the fold schedule needs three tiles");
     uint32_t c22;
     asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
     const uint32_t m88 = 0x88888888u;
-    mx_v8i ao[5];
-    if (STEADY) {
+    mx_v8i ao[5];                                    // two words: left operands of the leaving row; one word, before the steady state: an[2] with its second half zero
+    if constexpr (WORDS == 2) {
+        if (STEADY) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) ao[k] = mx_frag(cur_l[G::RPX + k]);
+            for (int k = 0; k < 5; ++k) ao[k] = mx_frag(ptr.cur_l[G::RPX + k]);
+        }
+    } else if constexpr (!STEADY) {
+        ao[2] = an[2];
+        if (lane >= 32) ao[2] = mx_v8i{0, 0, 0, 0, 0, 0, 0, 0};
     }
     auto right = [&](int s) -> uint4 {               // right operand of matrix instruction s; s >= S: of the next row's instruction s - S
         const bool next = s >= S;
         const int s2 = next ? s - S : s, t = s2 / PER, j = s2 % PER, k = j % 5;
-        return (next ? nxt_e : j >= 5 ? cur_l : cur_e)[32 * t + k];
+        if constexpr (WORDS == 2) return (next ? ptr.nxt_e : j >= 5 ? ptr.cur_l : ptr.cur_e)[32 * t + k];
+        else return (next ? ptr.nxt[j] : ptr.cur[j])[32 * t];
     };
     float rx[5];
     __builtin_amdgcn_sched_barrier(0);
     mx_static_for(std::make_integer_sequence<int, S>{}, [&](auto s_c) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value;
         constexpr int t = s / PER, j = s % PER, k = j % 5;
-        const mx_v8i b = mx_frag(fb[s % P]);
-        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(j >= 5 ? ao[k] : an[k], b, acc[t], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        if constexpr (WORDS == 2 || STEADY || j <= 2) {
+            const mx_v8i b = mx_frag(fb[s % P]);
+            const mx_v8i a = WORDS == 2 ? (j >= 5 ? ao[k] : an[k]) : (!STEADY && j == 2 ? ao[2] : an[j]);
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[t], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
         asm volatile("" : "+v"(acc[t]));      // keeps the instruction at this place among the ordered statements around it
         if constexpr (s == MEET) mx_meet();
         fb[s % P] = right(s + P);
-        if constexpr (s >= MEET && s < MEET + 5) an[s - MEET] = mx_frag(nxt_e[G::RPX + (s - MEET)]);   // its last use was this instruction
+        if constexpr (s >= MEET && s < MEET + 5) {   // the last use of this left operand was this instruction
+            if constexpr (WORDS == 2) an[s - MEET] = mx_frag(ptr.nxt_e[G::RPX + (s - MEET)]);
+            else an[s - MEET] = mx_frag(ptr.nxt[s - MEET][G::RPX]);
+        }
 
         // this thread's share of the next staged rows
         mx_static_for(std::make_integer_sequence<int, 2 * G::ROUNDS>{}, [&](auto v_c) __attribute__((always_inline)) {
             constexpr int v = decltype(v_c)::value;
-            if constexpr (mx_unit_step<T, STEADY>(v) == s && !(MX_X & 1)) {
+            if constexpr (mx_unit_step<T, WORDS, PER>(v) == s && !(MX_X & 1)) {
                 constexpr bool old = v >= G::ROUNDS;                  // entering row first, then the leaving row
                 constexpr int i = old ? v - G::ROUNDS : v;
                 auto unit = [&](bool lane_has_word) __attribute__((always_inline)) {
@@ -251,7 +277,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *cur_e, co
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.y) : "v"(w << 2), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.z) : "v"(w << 1), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.w) : "v"(w), "s"(m88), "v"(c22));
-                    if (lane_has_word) (old ? stage_l : stage_e)[st.slot0 + i * (32 * MX_W)] = e;
+                    if (lane_has_word) (old ? stage_l : stage_e)[st.slot0 + i * G::ROUND_PX] = e;
                     if constexpr (old) st.wo[i] = st.src[i][off_old]; else st.wn[i] = st.src[i][off_new];
                 };
                 if constexpr (i < G::FULL_ROUNDS) unit(true);
@@ -259,7 +285,9 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *cur_e, co
             }
         });
 
-        if constexpr (STEADY && !(MX_X & 2)) {
+        // the winners of the previous output: a timetable of ten slots per tile; with five instructions per tile each takes two
+        auto select = [&](auto j_c) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_c)::value;
             // left view
             // (five tiles: two three-way maxima per element; fewer tiles: tile by tile)
             if constexpr (T == 5) {
@@ -301,6 +329,10 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const uint4 *cur_e, co
                     if constexpr (t == 0) st.part += st.part_stride;  // the following tiles belong to this row
                 }
             }
+        };
+        if constexpr (STEADY && !(MX_X & 2)) {
+            if constexpr (PER == 10) select(std::integral_constant<int, j>{});
+            else { select(std::integral_constant<int, 2 * j>{}); select(std::integral_constant<int, 2 * j + 1>{}); }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -357,11 +389,11 @@ __device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<
 // writes image (r + 1) % 3; a wavefront that is ahead of the others has passed the meeting point of row r - 1 at
 // least, so every wavefront has finished reading the image it overwrites (last read by row r - 2), and what it reads
 // behind the meeting point of row r (the next image) is complete.
-template <int T, bool BOTH, bool EDGE>
+template <int T, int WORDS, bool BOTH, bool EDGE>
 __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
                                          int cols, int max_disp, int d_base, int pass_flags, int xl0, int xl0_wg, int own_from, int y_lo, int n_rows, int tid,
                                          float *__restrict__ disp, float *__restrict__ part_row0, long part_stride) {
-    using G = MxGeom<T>;
+    using G = MxGeom<T, WORDS>;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
     const int r0 = xl0 - 32 * (T - 1) - d_base;      // right column of tile 0, lane 0 (this pass searches disparities d_base .. d_base + 32 (T - 1) - 1)
@@ -389,25 +421,25 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.pen_r[i] = xl0 + (i & 3) + 8 * (i >> 2) + 4 * h <= cols - 6 ? 0.0f : -2097152.0f;
 
-    // staging: word q of a staged row is right word (xl0_wg - 32 (T - 1) - d_base - 2) * 2 + q for q < 2 RPX, left word
-    // (xl0_wg - 2) * 2 + q - 2 RPX after it; thread tid takes the words tid, tid + 256, ...  Words outside the frame
-    // are clamped into it: left of the frame they only feed inadmissible pairs, right of it (the columns behind the
+    // staging: word q of a staged row is right word (xl0_wg - 32 (T - 1) - d_base - 2) * WORDS + q for q < WORDS RPX, left
+    // word (xl0_wg - 2) * WORDS + q - WORDS RPX after it; thread tid takes the words tid, tid + 256, ...  Words outside the
+    // frame are clamped into it: left of the frame they only feed inadmissible pairs, right of it (the columns behind the
     // last x-block of a workgroup that the frame does not fill) nothing reads them.
-    const long row_words = (long)cols * 2;
+    const long row_words = (long)cols * WORDS;
     const uint32_t *const cl0 = cl + (long)(y_lo - 2) * row_words, *const cr0 = cr + (long)(y_lo - 2) * row_words;
 #pragma unroll
     for (int i = 0; i < G::ROUNDS; ++i) {
-        const int q = min(i * (64 * MX_W) + tid, G::WORDS - 1);
-        const bool is_left = q >= 2 * G::RPX;
-        const long wr = min(max((long)(xl0_wg - 32 * (T - 1) - d_base - 2) * 2 + q, 0L), row_words - 1);
-        const long wl = min(max((long)(xl0_wg - 2) * 2 + (q - 2 * G::RPX), 0L), row_words - 1);
+        const int q = min(i * (64 * MX_W) + tid, G::NWORDS - 1);
+        const bool is_left = q >= WORDS * G::RPX;
+        const long wr = min(max((long)(xl0_wg - 32 * (T - 1) - d_base - 2) * WORDS + q, 0L), row_words - 1);
+        const long wl = min(max((long)(xl0_wg - 2) * WORDS + (q - WORDS * G::RPX), 0L), row_words - 1);
         st.src[i] = is_left ? cl0 + wl : cr0 + wr;
         st.flip[i] = is_left ? 0xffffffffu : 0u;
     }
     auto word = [&](int i, int r) -> uint32_t { return st.src[i][r * row_words]; };   // word of staging round i in census row r of the strip
-    st.slot0 = (tid & 1) * G::PLANE + (tid >> 1);
-    st.tail_wave = (G::ROUNDS - 1) * (64 * MX_W) + wave * 64 < G::WORDS;
-    st.tail_lane = (G::ROUNDS - 1) * (64 * MX_W) + tid < G::WORDS;
+    st.slot0 = WORDS == 2 ? (tid & 1) * G::PLANE + (tid >> 1) : tid;
+    st.tail_wave = (G::ROUNDS - 1) * (64 * MX_W) + wave * 64 < G::NWORDS;
+    st.tail_lane = (G::ROUNDS - 1) * (64 * MX_W) + tid < G::NWORDS;
     const int last = n_rows - 1;
     const int i_out = lane & 15;
     st.out = disp + (long)y_lo * cols + xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h;
@@ -416,10 +448,27 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     st.part = part_row0 + n;
     st.part_stride = part_stride;
 
-    // image b: entering row at lds + 2 b SLOTS, leaving row behind it; a lane reads at its pixel offset `rd`
-    const int rd = h * G::PLANE + (xl0 - xl0_wg) + n;
+    // image b: entering row at lds + 2 b SLOTS, leaving row behind it
     auto img_e = [&](int b) -> uint4 * { return lds + (2 * b) * G::SLOTS; };
     auto img_l = [&](int b) -> uint4 * { return lds + (2 * b + 1) * G::SLOTS; };
+    // Read positions of this lane.  Two-word descriptors: its pixel in the plane of its k-half.  One-word descriptors: for
+    // instruction j of a tile the window pixel its k-half takes: (e0,e1) (e2,e3) (e4,l0) (l1,l2) (l3,l4).
+    const int rd = (WORDS == 2 ? h * G::PLANE : 0) + (xl0 - xl0_wg) + n;
+    int rd1[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int slot = 2 * j + h;                  // 0..4: entering row's window column, 5..9: the leaving row's
+        rd1[j] = (slot >= 5 ? G::SLOTS + slot - 5 : slot) + rd;
+    }
+    MxPtrs<WORDS> ptr;
+    auto point = [&](int b_cur, int b_nxt) {
+        if constexpr (WORDS == 2) {
+            ptr.cur_e = img_e(b_cur) + rd; ptr.cur_l = img_l(b_cur) + rd; ptr.nxt_e = img_e(b_nxt) + rd;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { ptr.cur[j] = img_e(b_cur) + rd1[j]; ptr.nxt[j] = img_e(b_nxt) + rd1[j]; }
+        }
+    };
 
     // row 0 is staged here, every other row while its predecessor runs
     {
@@ -427,35 +476,39 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
 #pragma unroll
         for (int i = 0; i < G::ROUNDS; ++i)
-            if (i < G::FULL_ROUNDS || st.tail_lane) img_e(0)[st.slot0 + i * (32 * MX_W)] = mx_expand(word(i, 0), c22);
+            if (i < G::FULL_ROUNDS || st.tail_lane) img_e(0)[st.slot0 + i * G::ROUND_PX] = mx_expand(word(i, 0), c22);
 #pragma unroll
         for (int i = 0; i < G::ROUNDS; ++i) { st.wn[i] = word(i, 1); st.wo[i] = 0u; }
     }
     __syncthreads();
+    int b_cur = 0, b_nxt = 1;
+    point(b_cur, b_nxt);
     mx_v8i an[5];
     uint4 fb[MX_P];
+    static_assert(MX_P == 5, "the first operands of a row are those of its first tile's five products");
 #pragma unroll
-    for (int k = 0; k < 5; ++k) an[k] = mx_frag(img_e(0)[rd + G::RPX + k]);
-#pragma unroll
-    for (int s = 0; s < MX_P; ++s) fb[s] = img_e(0)[rd + s];          // tile 0, window columns 0 .. MX_P-1 (MX_P <= 5)
-    static_assert(MX_P <= 5, "the first operands of a row are those of its first tile's entering products");
+    for (int k = 0; k < 5; ++k) {                    // tile 0: left operands and the first MX_P right operands
+        if constexpr (WORDS == 2) { an[k] = mx_frag(ptr.cur_e[G::RPX + k]); fb[k] = ptr.cur_e[k]; }
+        else { an[k] = mx_frag(ptr.cur[k][G::RPX]); fb[k] = ptr.cur[k][0]; }
+    }
 
     // row r stages row r+1 (entering) with row r-4 (leaving) and fetches the words of rows r+2 and r-3
-    int b_cur = 0, b_nxt = 1;
 #pragma unroll 1
     for (int r = 0; r < 5; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)max(r - 3, 0) * row_words;
-        mx_row<T, false, BOTH, EDGE>(acc, img_e(b_cur) + rd, img_l(b_cur) + rd, img_e(b_nxt) + rd, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32, pass_flags);
+        mx_row<T, WORDS, false, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32, pass_flags);
         b_cur = b_nxt;
         b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
+        point(b_cur, b_nxt);
     }
     mx_first_output<T, BOTH, EDGE>(acc, st, swap32);
 #pragma unroll 1
     for (int r = 5; r < n_rows; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)(r - 3) * row_words;
-        mx_row<T, true, BOTH, EDGE>(acc, img_e(b_cur) + rd, img_l(b_cur) + rd, img_e(b_nxt) + rd, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32, pass_flags);
+        mx_row<T, WORDS, true, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32, pass_flags);
         b_cur = b_nxt;
         b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
+        point(b_cur, b_nxt);
     }
     mx_last_output<T, BOTH, EDGE>(acc, st, lane, swap32, pass_flags);
 }
@@ -467,11 +520,11 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
 // mx_reduce_tail).  Requires cols >= 36, rows >= 5.
 // BOTH: also stores, for every output row and x-block, the right view's best key of each of the block's 32 T right
 // columns over the block's left columns: partial[frame][row][x-block][32 T] (svx_mx_right_disparity merges them).
-template <int T, bool BOTH>
+template <int T, int WORDS, bool BOTH>
 __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                           int rows, int cols, int max_disp, int d_base, int pass_flags, int strip_rows, int n_xblocks,
                                                           float *__restrict__ disp_all, int write_border, float *__restrict__ partial) {
-    using G = MxGeom<T>;
+    using G = MxGeom<T, WORDS>;
     __shared__ uint4 lds[MX_NBUF * 2 * G::SLOTS];    // [image][entering row, leaving row][see MxGeom]
     const int tid = threadIdx.x, lane = tid & 63;
     const int n = lane & 31, h = lane >> 5;
@@ -480,8 +533,8 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     if ((total & 7u) == 0u) wi = (wi & 7u) * (total >> 3) + (wi >> 3);      // contiguous run of work items per XCD
     const unsigned gx = wi % gridDim.x, by = (wi / gridDim.x) % gridDim.y, bz = wi / (gridDim.x * gridDim.y);
     const long npx = (long)rows * cols;
-    const uint32_t *cl = cl_all + bz * npx * 2;
-    const uint32_t *cr = cr_all + bz * npx * 2;
+    const uint32_t *cl = cl_all + bz * npx * WORDS;
+    const uint32_t *cr = cr_all + bz * npx * WORDS;
     float *disp = disp_all + bz * npx;
     const int bx_wave = (int)gx * MX_W + __builtin_amdgcn_readfirstlane(tid >> 6), bx = min(bx_wave, n_xblocks - 1);
     // left columns from own_from on are this wavefront's to write: the last x-block is shifted over its neighbour, and a
@@ -494,8 +547,8 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)bx * (32 * T) : nullptr;
     // blocks in which the two views admit different pairs
     const bool edge = BOTH && (xl0 - 32 * (T - 1) - d_base < 5 || xl0 + MX_M - 1 > cols - 6);
-    if (edge) mx_strip<T, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
-    else mx_strip<T, BOTH, false>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    if (edge) mx_strip<T, WORDS, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    else mx_strip<T, WORDS, BOTH, false>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
 
     if (write_border) {
         // rows outside [2, rows-2) over this block's columns, and the two border columns on either side
@@ -576,10 +629,10 @@ bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX
 // passes of 128 disparities with five tiles (two wavefronts per SIMD; nine tiles in one pass leave room for one, which is
 // slower per disparity), unless SVX_OPT_MX_WIDE_TILES asks for the nine-tile kernel at up to 256.
 struct MxPlan { int tiles, passes; };
-static MxPlan mx_plan(const svx_ctx *ctx, int max_disp) {
+static MxPlan mx_plan(const svx_ctx *ctx, int max_disp, int words = 2) {
     if (max_disp <= 64) return {3, 1};
     if (max_disp <= 128) return {5, 1};
-    if (max_disp <= 256 && svx_opt(ctx, SVX_OPT_MX_WIDE_TILES) == 1) return {9, 1};
+    if (max_disp <= 256 && words == 2 && svx_opt(ctx, SVX_OPT_MX_WIDE_TILES) == 1) return {9, 1};
     return {5, (max_disp + 127) / 128};
 }
 static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }
@@ -591,9 +644,9 @@ size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames
 
 // Left-view search on two-word descriptors; see svx_dense.hip for the meaning of the arguments.
 // partial != nullptr: also the right view's partial keys (svx_mx_partial_words floats).
-int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp,
+int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp,
                         float *disparity, int write_border, float *partial) {
-    const MxPlan plan = mx_plan(ctx, max_disp);
+    const MxPlan plan = mx_plan(ctx, max_disp, words);
     const int T = plan.tiles;
     // Strips: every strip re-reads 4 halo rows and starts with 5 rows that fill the window, but the grid should fill the
     // chip a whole number of times (8 wavefronts or, with nine tiles, 4 fit a CU): take the
@@ -621,12 +674,19 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
         const int d_base = p * 32 * (T - 1), flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes ? 2 : 0);
         const int wb = p + 1 == plan.passes ? write_border : 0;
         float *part = partial ? partial + p * pass_words : nullptr;
-        if (T == 9 && !partial) dense_wta_mx_kernel<9, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, nullptr);
-        else if (T == 9) dense_wta_mx_kernel<9, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, part);
-        else if (T == 3 && !partial) dense_wta_mx_kernel<3, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, nullptr);
-        else if (T == 3) dense_wta_mx_kernel<3, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, part);
-        else if (!partial) dense_wta_mx_kernel<5, false><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, nullptr);
-        else dense_wta_mx_kernel<5, true><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, part);
+#define MX_LAUNCH(TT, WW, BB, PART) dense_wta_mx_kernel<TT, WW, BB><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, PART)
+        if (words == 1) {
+            if (T == 3 && !partial) MX_LAUNCH(3, 1, false, nullptr);
+            else if (T == 3) MX_LAUNCH(3, 1, true, part);
+            else if (!partial) MX_LAUNCH(5, 1, false, nullptr);
+            else MX_LAUNCH(5, 1, true, part);
+        } else if (T == 9 && !partial) MX_LAUNCH(9, 2, false, nullptr);
+        else if (T == 9) MX_LAUNCH(9, 2, true, part);
+        else if (T == 3 && !partial) MX_LAUNCH(3, 2, false, nullptr);
+        else if (T == 3) MX_LAUNCH(3, 2, true, part);
+        else if (!partial) MX_LAUNCH(5, 2, false, nullptr);
+        else MX_LAUNCH(5, 2, true, part);
+#undef MX_LAUNCH
         SVX_LAUNCH_CHECK(ctx, "dense_wta_mx_kernel");
     }
     return SVX_OK;
@@ -634,11 +694,11 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
 
 // After svx_launch_mx_sweep with partial keys: the right disparity map (disp_right != nullptr) or the left-right
 // check of disp_left in place.
-int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int max_disp,
+int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int words, int max_disp,
                         float *disp_left, float *disp_right, float lr_threshold) {
     const dim3 grid(svx_cdiv(cols, 256), rows, n_frames);
     const int nb = mx_xblocks(cols);
-    const MxPlan plan = mx_plan(ctx, max_disp);
+    const MxPlan plan = mx_plan(ctx, max_disp, words);
     const long ps = (long)n_frames * rows * nb * 32 * plan.tiles;
     const int np = plan.passes;
     if (plan.tiles == 9) {
@@ -666,13 +726,13 @@ SVX_API int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, cons
     SVX_REQUIRE(ctx, n_frames >= 1 && n_frames <= 65535 && rows <= 65535, SVX_ERR_INVALID_ARG, "svx_dense_wta_matrix: bad frame count or size");
     SVX_REQUIRE(ctx, svx_mx_sweep_eligible(rows, cols, max_disp), SVX_ERR_UNSUPPORTED,
                 "svx_dense_wta_matrix: needs cols >= 36, rows >= 5, 1 <= max_disp <= 1024");
-    if (!disp_right) return svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, nullptr);
+    if (!disp_right) return svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, 2, max_disp, disp_left, 1, nullptr);
     const size_t per_frame = svx_mx_partial_words(ctx, rows, cols, 1, max_disp);
     SVX_REQUIRE(ctx, per_frame * n_frames * sizeof(float) <= ((size_t)4 << 30), SVX_ERR_UNSUPPORTED, "svx_dense_wta_matrix: batch too large for one call");
     void *ws;
     rc = svx_ws_reserve(ctx, per_frame * n_frames * sizeof(float), &ws);
     if (rc) return rc;
-    rc = svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, (float *)ws);
+    rc = svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, 2, max_disp, disp_left, 1, (float *)ws);
     if (rc) return rc;
-    return svx_launch_mx_right(ctx, (const float *)ws, rows, cols, n_frames, max_disp, disp_left, disp_right, 0.0f);
+    return svx_launch_mx_right(ctx, (const float *)ws, rows, cols, n_frames, 2, max_disp, disp_left, disp_right, 0.0f);
 }

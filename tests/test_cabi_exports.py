@@ -49,8 +49,9 @@ def test_dense_kernel_choice_is_a_host_side_query():
     assert lib.svx_dense_kernel_choice(None, 1072, 1920, 2, 256, 1) == 1
     assert lib.svx_dense_kernel_choice(None, 2160, 3840, 2, 512, 1) == 1     # more than 128 disparities: passes of 128
     assert lib.svx_dense_kernel_choice(None, 2160, 3840, 2, 1025, 1) == 2    # beyond what the keys' disparity tag holds
-    assert lib.svx_dense_kernel_choice(None, 368, 1232, 1, 128, 1) == 0      # one-word descriptors
-    assert lib.svx_dense_kernel_choice(None, 368, 1232, 2, 128, 0) == 0      # single view
+    assert lib.svx_dense_kernel_choice(None, 368, 1232, 1, 128, 1) == 1      # one-word descriptors
+    assert lib.svx_dense_kernel_choice(None, 368, 1232, 2, 128, 0) == 1      # single view
+    assert lib.svx_dense_kernel_choice(None, 368, 30, 2, 128, 0) == 0        # too narrow for the matrix-core search: vector sweep
     assert lib.svx_dense_kernel_choice(None, 4, 1232, 2, 128, 0) == 2
     assert S.dense_kernel_name(368, 1232, 2, 128, True) == "dense_wta_mx_kernel"
 

@@ -43,14 +43,19 @@ def test_census9x7(ctx, rows, cols):
 @pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (12, 40, 64), (30, 150, 128), (9, 21, 5), (5, 20, 8), (16, 300, 200),
                                                  (110, 90, 70), (8, 19, 4), (4, 30, 4), (20, 70, 1100)])
 @pytest.mark.parametrize("words", [1, 2])
-@pytest.mark.parametrize("view", [0, 1])
-def test_dense_wta_matches_oracle(ctx, rows, cols, max_disp, words, view):
+@pytest.mark.parametrize("view,matrix_cores", [(0, -1), (0, 0), (1, -1)])     # left view: matrix-core search and vector sweep; right view: sweep only
+def test_dense_wta_matches_oracle(ctx, rows, cols, max_disp, words, view, matrix_cores):
+    import stereovision_amd as S
     rng = np.random.default_rng(rows * 1000 + cols + max_disp + words)
     shape = (2, rows, cols) + ((2,) if words == 2 else ())
     # few distinct values give many cost ties, which exercise the first-minimum rule in both views
     cl = rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x01010101 if cols % 2 else 0xffffffff)
     cr = np.roll(cl, -3, axis=2) ^ (rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x00010000))
-    got = ctx.dense_wta(dev_u32(cl), dev_u32(cr), max_disp, view=view, words=words).cpu().numpy()
+    ctx.set_option(S.OPT_MATRIX_CORES, matrix_cores)
+    try:
+        got = ctx.dense_wta(dev_u32(cl), dev_u32(cr), max_disp, view=view, words=words).cpu().numpy()
+    finally:
+        ctx.set_option(S.OPT_MATRIX_CORES, -1)
     for f in range(2):
         want = O.dense_wta_words(cl[f], cr[f], max_disp, view)
         assert np.array_equal(got[f], want), (f, np.argwhere(got[f] != want)[:5])
@@ -59,13 +64,20 @@ def test_dense_wta_matches_oracle(ctx, rows, cols, max_disp, words, view):
 @pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (12, 40, 64), (30, 150, 128), (9, 21, 5), (5, 20, 8), (16, 300, 200),
                                                  (110, 90, 70), (8, 19, 4), (4, 30, 4), (20, 70, 1100), (40, 333, 128), (7, 1232, 128)])
 @pytest.mark.parametrize("words", [1, 2])
-def test_dense_wta_both_views_from_one_sweep(ctx, rows, cols, max_disp, words):
-    """The right view taken from the left sweep's cost values equals the oracle's right-view search (ties included)."""
+@pytest.mark.parametrize("matrix_cores", [-1, 0])
+def test_dense_wta_both_views_from_one_sweep(ctx, rows, cols, max_disp, words, matrix_cores):
+    """The right view taken from the left sweep's cost values equals the oracle's right-view search (ties included), with
+    the matrix-core search and with the vector sweep."""
+    import stereovision_amd as S
     rng = np.random.default_rng(rows * 1000 + cols + max_disp + words + 5)
     shape = (2, rows, cols) + ((2,) if words == 2 else ())
     cl = rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x01010101 if cols % 2 else 0xffffffff)
     cr = np.roll(cl, -3, axis=2) ^ (rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32) & np.uint32(0x00010000))
-    dl, dr = ctx.dense_wta_both(dev_u32(cl), dev_u32(cr), max_disp, words=words)
+    ctx.set_option(S.OPT_MATRIX_CORES, matrix_cores)
+    try:
+        dl, dr = ctx.dense_wta_both(dev_u32(cl), dev_u32(cr), max_disp, words=words)
+    finally:
+        ctx.set_option(S.OPT_MATRIX_CORES, -1)
     dl, dr = dl.cpu().numpy(), dr.cpu().numpy()
     for f in range(2):
         wl, wr = O.dense_wta_words(cl[f], cr[f], max_disp, 0), O.dense_wta_words(cl[f], cr[f], max_disp, 1)
@@ -103,6 +115,40 @@ def test_dense_wta_matrix_close_costs(ctx, rows, cols, max_disp):
     want_l, want_r = O.dense_wta_words(cl, cr, max_disp, 0), O.dense_wta_words(cl, cr, max_disp, 1)
     assert np.array_equal(dl.cpu().numpy(), want_l), np.argwhere(dl.cpu().numpy() != want_l)[:5]
     assert np.array_equal(dr.cpu().numpy(), want_r), np.argwhere(dr.cpu().numpy() != want_r)[:5]
+
+
+@pytest.mark.parametrize("rows,cols,max_disp,frames", [(24, 64, 16, 2), (40, 420, 64, 1), (23, 300, 128, 2), (12, 900, 400, 1), (9, 40, 5, 1),
+                                                        (368, 1232, 128, 2), (480, 640, 64, 1)])
+def test_one_word_search_on_the_matrix_cores(ctx, rows, cols, max_disp, frames):
+    """One-word (the reference's 24-bit 5x5) descriptors through the matrix-core search (two window pixels per instruction):
+    left view, and both views from one pass, against the oracle (small frames) or the vector sweep (large ones), and the
+    fused u8 entry point of the reference-pinned path."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    ls, rs = synth.stereo_batch(rows, cols, min(max_disp, max(2, cols // 3)), frames, seed0=rows + max_disp)
+    cl = np.stack([O.census5x5(O.u8_to_s8(a)) for a in ls]); cr = np.stack([O.census5x5(O.u8_to_s8(a)) for a in rs])
+    dcl, dcr = dev_u32(cl), dev_u32(cr)
+    ctx.set_option(S.OPT_MATRIX_CORES, 0)
+    try:
+        assert S.dense_kernel_name(rows, cols, 1, max_disp, False, ctx) != "dense_wta_mx_kernel"
+        wl, wr = ctx.dense_wta(dcl, dcr, max_disp, S.VIEW_LEFT, 1), ctx.dense_wta(dcl, dcr, max_disp, S.VIEW_RIGHT, 1)
+    finally:
+        ctx.set_option(S.OPT_MATRIX_CORES, -1)
+    if cols >= 36 and rows >= 5:
+        assert S.dense_kernel_name(rows, cols, 1, max_disp, False, ctx) == "dense_wta_mx_kernel"
+    ml = ctx.dense_wta(dcl, dcr, max_disp, S.VIEW_LEFT, 1)
+    bl, br = ctx.dense_wta_both(dcl, dcr, max_disp, words=1)
+    fused = ctx.dense_census_wta(dev(ls), dev(rs), max_disp)
+    assert torch.equal(ml, wl), (ml != wl).nonzero()[:5].tolist()
+    assert torch.equal(bl, wl) and torch.equal(br, wr), ((bl != wl).nonzero()[:3].tolist(), (br != wr).nonzero()[:3].tolist())
+    assert torch.equal(fused, wl)
+    if rows * cols <= 40000:
+        for f in range(frames):
+            assert np.array_equal(ml[f].cpu().numpy(), O.dense_wta_words(cl[f], cr[f], max_disp, 0))
+            assert np.array_equal(br[f].cpu().numpy(), O.dense_wta_words(cl[f], cr[f], max_disp, 1))
+    else:
+        y0 = rows // 2
+        assert np.array_equal(ml[0].cpu().numpy()[y0:y0 + 2], O.dense_wta_words(cl[0], cr[0], max_disp, 0, y0, y0 + 2)[y0:y0 + 2])
 
 
 def test_dense_wta_matrix_refuses_what_it_does_not_cover(ctx):
