@@ -23,7 +23,7 @@ typedef int mx_v8i __attribute__((ext_vector_type(8)));
 typedef float mx_v16f __attribute__((ext_vector_type(16)));
 
 #ifndef MX_X
-#define MX_X 0      // measurement aid: bit 0 drops the staging work, bit 1 the winner selection (results are wrong then)
+#define MX_X 0      // measurement aid: bit 0 drops the staging work, bit 1 the winner selection, bit 2 the meeting point (results are wrong then)
 #endif
 #ifndef MX_PLANE_PAD
 #define MX_PLANE_PAD 0      // measurement aid: extra pixels between the two planes of a staged row
@@ -144,7 +144,9 @@ struct MxState {
 
 // The workgroup's meeting point.  No wait is attached: what a wavefront must have finished (its staging writes) is
 // covered by the operand wait of the matrix instruction in front of it, and its pending global loads stay in flight.
-__device__ __forceinline__ void mx_meet() { asm volatile("s_barrier" ::: "memory"); }
+__device__ __forceinline__ void mx_meet() {
+    if (!(MX_X & 4)) asm volatile("s_barrier" ::: "memory");
+}
 
 // Accumulator element i of tile u as the left view (L) or the right view sees it.
 template <int T, bool EDGE>
