@@ -305,7 +305,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_w%d%s%s.json" % (words, "_both" if both_views else "",
                                                                                          "_mx" if on_matrix_cores else ""))))
             if tj["kernel"] == kernel_name and tj["words"] == words and F == 64 and D == 128:
-                traffic = (tj["fetch_size_kb"] + tj["write_size_kb"]) * 1024.0
+                traffic = (tj.get("fetch_correction", 1.0) * tj["fetch_size_kb"] + tj["write_size_kb"]) * 1024.0
         except Exception:
             traffic = None
         roofline = {
