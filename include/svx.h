@@ -70,12 +70,16 @@ int svx_synchronize(svx_ctx *ctx);
  *                                                  svx_pipeline_stage_times (default 0: no synchronisation, times 0)
  *   SVX_OPT_MX_WIDE_TILES    (SVX_MX_WIDE_TILES)   1 = 129..256 disparities in one pass of the nine-tile matrix-core kernel
  *                                                  instead of two passes of the five-tile one (default 0)
+ *   SVX_OPT_MESH_ON_DEVICE   (SVX_MESH_ON_DEVICE)  0 = svx_high_perf_stereo triangulates its support points on the host
+ *                                                  (svx_mesh_*); default 1 = on the device (svx_mesh_plane_prior_device);
+ *                                                  the triangles are the same
  * The one option that changes results:
  *   SVX_OPT_PRIOR_BAND_RADIUS (SVX_PRIOR_BAND_RADIUS) radius of svx_high_perf_stereo's search around the plane prior
  *                                                  (svx_cost_eval_band); default 0 = the reference's single disparity */
 enum svx_option {
     SVX_OPT_MATRIX_CORES = 0, SVX_OPT_LR_TWO_SWEEPS = 1, SVX_OPT_SWEEP_WAVES = 2, SVX_OPT_SWEEP_WAVES_BOTH = 3,
-    SVX_OPT_CENSUS97_PACKED = 4, SVX_OPT_MX_STRIP_ROWS = 5, SVX_OPT_STAGE_TIMES = 6, SVX_OPT_PRIOR_BAND_RADIUS = 7, SVX_OPT_MX_WIDE_TILES = 8, SVX_OPT_COUNT = 9
+    SVX_OPT_CENSUS97_PACKED = 4, SVX_OPT_MX_STRIP_ROWS = 5, SVX_OPT_STAGE_TIMES = 6, SVX_OPT_PRIOR_BAND_RADIUS = 7, SVX_OPT_MX_WIDE_TILES = 8,
+    SVX_OPT_MESH_ON_DEVICE = 9, SVX_OPT_COUNT = 10
 };
 int svx_set_option(svx_ctx *ctx, int option, int value);
 int svx_get_option(const svx_ctx *ctx, int option, int *value);   /* ctx NULL: the default a new context would get */
@@ -336,6 +340,19 @@ int svx_exfast_detect(svx_ctx *ctx, const uint8_t *img, int rows, int cols, int 
  * svx_mesh_plane_prior: triangulation, plane table (.cpp:454-466) and interpolation loop
  *   (.cpp:532-554) in one call: host support points, device disparities, device prior. */
 int svx_delaunay(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, int32_t *tri_idx_host, int capacity, int *n_tri);
+/* The same triangulation computed on the device (device points in, device index triples out, in svx_delaunay's
+ * order; *n_tri_host on the host, the call synchronises): every point finds the triangles around it from the points
+ * near it, and the points that cannot be sure (next to large empty areas, on the hull) from all points.  Points
+ * must lie inside a rows x cols frame of at most 8192 x 8192.  SVX_ERR_UNSUPPORTED for a point set with more than 64
+ * triangles around one point (or 32 led by one point): svx_delaunay takes those.
+ * svx_mesh_plane_prior_device is svx_mesh_plane_prior with the points on the device and the triangulation done there
+ * (it falls back to the host triangulation by itself where svx_delaunay_device would refuse).
+ * svx_mesh_device_stats: how many points of the context's last device triangulation needed a second look at a wider
+ * neighbourhood, and how many the pass over all points (a tuning aid; either pointer may be NULL). */
+int svx_delaunay_device(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, int rows, int cols, int32_t *tri_idx, int capacity, int *n_tri_host);
+int svx_mesh_plane_prior_device(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float *disparities, int rows, int cols,
+                                float *prior, int *n_tri_out);
+int svx_mesh_device_stats(const svx_ctx *ctx, int *left_by_first_pass, int *left_by_second_pass);
 
 /* The mesh as an object that grows, the role of the Fade_2D instance that highPerfStereo() keeps across its iterations
  * (insert: highPerfStereoLib.cpp:434-445 and, through supportResampling, :141-175; getTrianglePointers: :457).  Host

@@ -28,6 +28,7 @@ from ._lib import (  # noqa: F401
     OPT_STAGE_TIMES,
     OPT_PRIOR_BAND_RADIUS,
     OPT_MX_WIDE_TILES,
+    OPT_MESH_ON_DEVICE,
     EXPORTS,
     DOMINANT_KERNEL,
     dense_kernel_name,

@@ -10,7 +10,7 @@ EXFAST_NONMAX, EXFAST_THRESHOLD_ROUND_SAT = 1, 2
 VIEW_LEFT, VIEW_RIGHT = 0, 1
 WINDOW_5X6, WINDOW_5X5 = 0, 1
 # svx_option of include/svx.h
-OPT_MATRIX_CORES, OPT_LR_TWO_SWEEPS, OPT_SWEEP_WAVES, OPT_SWEEP_WAVES_BOTH, OPT_CENSUS97_PACKED, OPT_MX_STRIP_ROWS, OPT_STAGE_TIMES, OPT_PRIOR_BAND_RADIUS, OPT_MX_WIDE_TILES = range(9)
+OPT_MATRIX_CORES, OPT_LR_TWO_SWEEPS, OPT_SWEEP_WAVES, OPT_SWEEP_WAVES_BOTH, OPT_CENSUS97_PACKED, OPT_MX_STRIP_ROWS, OPT_STAGE_TIMES, OPT_PRIOR_BAND_RADIUS, OPT_MX_WIDE_TILES, OPT_MESH_ON_DEVICE = range(10)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _vp = C.c_void_p
@@ -65,6 +65,9 @@ EXPORTS = {
     "svx_exfast_detect": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, _i, _vp, _vp, _i, _vp]),
     "svx_delaunay": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]),
     "svx_mesh_plane_prior": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_i)]),
+    "svx_delaunay_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, C.POINTER(_i)]),
+    "svx_mesh_plane_prior_device": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_i)]),
+    "svx_mesh_device_stats": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "svx_point_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _i, C.POINTER(_i)]),
     "svx_dense_point_cloud": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_double, _vp, _vp, _i, _vp]),
     "svx_mesh_create": (_i, [_vp]),
@@ -571,6 +574,35 @@ class Context:
     def delaunay(self, pts_xy):
         """Host in, host out: [n_tri, 3] int32 index triples."""
         return delaunay(pts_xy)
+
+    def delaunay_device(self, pts_xy, rows, cols):
+        """Device in ([n, 2] int32), device out: [n_tri, 3] int32 index triples in svx_delaunay's order."""
+        t = self._torch
+        _check_dev(pts_xy, t.int32, "pts_xy")
+        n_pts = pts_xy.numel() // 2
+        tri = t.empty((max(2 * n_pts, 1), 3), dtype=t.int32, device=pts_xy.device)
+        n = _i(0)
+        self._call("svx_delaunay_device", _dptr(pts_xy), n_pts, rows, cols, _dptr(tri), tri.shape[0], C.byref(n))
+        return tri[:n.value]
+
+    def mesh_device_left_over(self):
+        """Points of the last device triangulation that needed the pass over all points."""
+        return self.mesh_device_stats()[1]
+
+    def mesh_device_stats(self):
+        """(points left by the first pass, points left by the second pass) of the last device triangulation."""
+        a, b = _i(0), _i(0)
+        self._call("svx_mesh_device_stats", C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def mesh_plane_prior_device(self, pts_xy, disparities, prior):
+        """svx_mesh_plane_prior with the points on the device.  Returns (prior, n_triangles)."""
+        t = self._torch
+        _check_dev(pts_xy, t.int32, "pts_xy"); _check_dev(disparities, t.float32, "disparities"); _check_dev(prior, t.float32, "prior")
+        n = _i(0)
+        self._call("svx_mesh_plane_prior_device", _dptr(pts_xy), pts_xy.numel() // 2, _dptr(disparities), disparities.shape[0],
+                   disparities.shape[1], _dptr(prior), C.byref(n))
+        return prior, n.value
 
     def mesh_plane_prior(self, pts_xy, disparities, prior):
         t = self._torch

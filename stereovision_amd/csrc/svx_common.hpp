@@ -27,6 +27,7 @@ struct svx_ctx {
     void *static_scratch;                   // this device's address of the code object's fixed scratch array (svx_dense.hip)
     hipEvent_t pinned_read;                 // recorded behind the last asynchronous copy out of `pinned`
     bool pinned_busy;
+    int mesh_left_over, mesh_left_first;    // svx_mesh_dev.hip: points of the last device triangulation that needed the pass over all points / a second look
 };
 
 // Default of an option: its environment variable when set, else the built-in value.
@@ -73,6 +74,8 @@ int svx_pinned_mark_read(svx_ctx *ctx);
 // Grows a device block kept in the context (pointer and size fields passed in) to at least `bytes`.
 int svx_block_reserve(svx_ctx *ctx, void **block, size_t *block_bytes, size_t bytes, const char *what);
 int svx_enter(svx_ctx *ctx);
+int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int rows, int cols, int32_t **tri_xy_out, int32_t **tri_idx_out,
+                              float **abc_out, int *n_tri);      // svx_mesh_dev.hip
 int svx_static_scratch_locate(svx_ctx *ctx);   // svx_dense.hip: finds this device's copy of the fixed scratch array
 
 // Matrix-core form of the dense search on two-word descriptors (svx_dense_mx.hip).

@@ -75,6 +75,7 @@ static const struct { int builtin; const char *env; } svx_option_table[SVX_OPT_C
     /* SVX_OPT_STAGE_TIMES */ {0, "SVX_STAGE_TIMES"},
     /* SVX_OPT_PRIOR_BAND_RADIUS */ {0, "SVX_PRIOR_BAND_RADIUS"},
     /* SVX_OPT_MX_WIDE_TILES */ {0, "SVX_MX_WIDE_TILES"},
+    /* SVX_OPT_MESH_ON_DEVICE */ {1, "SVX_MESH_ON_DEVICE"},
 };
 
 int svx_option_default(int option) {
@@ -140,6 +141,7 @@ SVX_API int svx_create(int device, svx_ctx **out) {
     c->tri_bytes = 0;
     c->pinned_read = nullptr;
     c->pinned_busy = false;
+    c->mesh_left_over = c->mesh_left_first = 0;
     for (int o = 0; o < SVX_OPT_COUNT; ++o) c->opt[o] = svx_option_default(o);
     c->workers = nullptr;
     c->n_workers = 0;

@@ -1,0 +1,616 @@
+// Support-point mesh on the device: the Delaunay triangulation of svx_mesh.hip (the stand-in for the Fade_2D object of
+// highPerfStereo/highPerfStereoLib.cpp:434-445, :457) computed point by point instead of by insertion.
+//
+// With the cocircular cases resolved by the symbolic perturbation of svx_mesh.hip (in_circle_tie: the point with the
+// smallest index is lifted most) the triangulation is a function of the point list alone, so every point can find the
+// triangles around it on its own, from exact integer predicates:
+//   * its nearest neighbour a0 is joined to it by a Delaunay edge (the disc on that diameter holds no other point);
+//   * given a Delaunay edge (p, a), the triangle to its left is (p, a, b) with b the point left of p -> a that no other
+//     such point c beats (c beats b when it lies inside the circle through p, a, b): one pass over the candidates;
+//   * walking a -> b until a0 comes back gives all triangles around p; when a side has no point (p is on the hull) the
+//     walk is finished clockwise from a0.
+// Candidates: the points are binned into square cells of about one point each (4 to 64 pixels a side); a point first
+// looks at the 7 x 7 cells around its own, which hold every point within three cells of it (more towards the image
+// border, where nothing lies outside).  A triangle found among them is the true one when its circumcircle lies within
+// that range (p is on the circle, so twice the radius bounds how far the circle reaches from p), and a point whose
+// triangles all pass owns its true ring.  Points that fail (next to empty areas, on the hull) look again at 21 x 21
+// cells, and what still fails is done by a workgroup each against ALL points.  A triangle is reported by its vertex of
+// smallest index, rotated to lead with it, and the list is ordered by (v0, v1, v2): the form svx_delaunay returns.
+#include "svx_common.hpp"
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int MAX_RING = 64;              // triangles around one point; a longer ring sends the call back to the host triangulation
+constexpr int MAX_LEAD = 32;              // triangles one point leads (it has the smallest index of the three)
+
+struct DPt { int x, y, id; };
+
+__device__ __forceinline__ DPt unpack(int2 c) { DPt p; p.x = c.x & 0xffff; p.y = (int)((unsigned)c.x >> 16); p.id = c.y; return p; }
+
+// Coordinates lie in [0, 8192): differences below 2^13, cross products below 2^27 (32-bit), the circle determinant below 2^57.
+__device__ __forceinline__ int d_orient(const DPt &a, const DPt &b, const DPt &c) { return (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x); }
+
+// > 0 when d lies inside the circle through a, b, c (counter-clockwise), cocircular cases by the rule of svx_mesh.hip
+// (in_circle_small, in_circle_tie there): never 0 for four distinct positions.
+__device__ __forceinline__ int d_in_circle(const DPt &a, const DPt &b, const DPt &c, const DPt &d) {
+    const int ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+    const long long a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+    const long long det = a2 * (long long)(bx * cy - by * cx) - b2 * (long long)(ax * cy - ay * cx) + c2 * (long long)(ax * by - ay * bx);
+    if (det != 0) return det > 0 ? 1 : -1;
+    const int m = min(min(a.id, b.id), min(c.id, d.id));
+    int o;
+    if (m == a.id) o = d_orient(b, c, d);
+    else if (m == b.id) o = -d_orient(a, c, d);
+    else if (m == c.id) o = d_orient(a, b, d);
+    else o = -d_orient(a, b, c);
+    return o > 0 ? 1 : (o < 0 ? -1 : 0);
+}
+
+// Does the circle through p, a, b stay within distance `reach` of p?  It does when its diameter is at most `reach`:
+// 4 r^2 = |pa|^2 |pb|^2 |ab|^2 / cross^2 <= reach^2, evaluated in double with a margin on the safe side.
+__device__ __forceinline__ bool circle_within(const DPt &p, const DPt &a, const DPt &b, int reach) {
+    if (reach < 0) return true;                                  // nothing lies outside the staged region
+    const double la = (double)((a.x - p.x) * (a.x - p.x) + (a.y - p.y) * (a.y - p.y));
+    const double lb = (double)((b.x - p.x) * (b.x - p.x) + (b.y - p.y) * (b.y - p.y));
+    const double lc = (double)((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y));
+    const double cr = (double)d_orient(p, a, b);
+    return la * lb * lc <= (double)reach * (double)reach * cr * cr * 0.999999;
+}
+
+// The circle through p, a, b as centre (relative to p) and squared radius in double, a little enlarged: a candidate
+// outside it cannot beat b, so the exact test is only evaluated for the few candidates inside (points ON the circle, the
+// cocircular ties, stay inside the enlarged one: double arithmetic is exact here up to rounding of the quotient).
+struct Circle {
+    double ox, oy, r2;
+    __device__ void set(const DPt &p, const DPt &a, const DPt &b) {
+        const double ax = a.x - p.x, ay = a.y - p.y, bx = b.x - p.x, by = b.y - p.y;
+        const double la = ax * ax + ay * ay, lb = bx * bx + by * by, inv = 0.5 / (ax * by - ay * bx);
+        ox = (by * la - ay * lb) * inv; oy = (ax * lb - bx * la) * inv;
+        r2 = (ox * ox + oy * oy) * (1.0 + 1e-9);
+    }
+    __device__ bool outside(const DPt &p, int cxy) const {
+        const double dx = (double)((cxy & 0xffff) - p.x) - ox, dy = (double)((int)((unsigned)cxy >> 16) - p.y) - oy;
+        return dx * dx + dy * dy > r2;
+    }
+};
+
+// In-place exclusive scan of v[0..n) by one workgroup, sixteen consecutive values per thread and round; v[n] receives the total.
+__global__ __launch_bounds__(1024) void scan16_kernel(unsigned *__restrict__ v, int n) {
+    __shared__ unsigned wave_tot[16];
+    __shared__ unsigned carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 16384) {
+        const int i0 = base + 16 * (int)threadIdx.x;
+        unsigned x[16];
+        unsigned sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { x[k] = i0 + k < n ? v[i0 + k] : 0u; sum += x[k]; }
+        unsigned incl = sum;                              // inclusive scan of the threads' sums inside the wavefront
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        unsigned run = before + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { if (i0 + k < n) v[i0 + k] = run; run += x[k]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) v[n] = carry;
+}
+
+// ---- binning ----
+// (a point outside the image raises counters[2] and is left out; the call then fails, but nothing is indexed with it)
+__global__ void cell_count_kernel(const int32_t *__restrict__ xy, int n, int rows, int cols, int shift, int gw, unsigned *__restrict__ cell_count, int *__restrict__ counters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    if (x < 0 || x >= cols || y < 0 || y >= rows) { atomicOr(&counters[2], 1); return; }
+    atomicAdd(&cell_count[(y >> shift) * gw + (x >> shift)], 1u);
+}
+
+__global__ void cell_fill_kernel(const int32_t *__restrict__ xy, int n, int rows, int cols, int shift, int gw, const unsigned *__restrict__ cell_start,
+                                 unsigned *__restrict__ cell_fill, int2 *__restrict__ binned) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    if (x < 0 || x >= cols || y < 0 || y >= rows) return;
+    const int cell = (y >> shift) * gw + (x >> shift);
+    const unsigned slot = cell_start[cell] + atomicAdd(&cell_fill[cell], 1u);
+    binned[slot] = make_int2(x | (y << 16), i);
+}
+
+// A repeated position is represented by its first index: the later copies get index -1 and take no part.
+__global__ void mark_repeats_kernel(int n, int shift, int gw, const unsigned *__restrict__ cell_start, int2 *__restrict__ binned, int *__restrict__ dead) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int2 me = binned[i];
+    if (me.y < 0) { dead[i] = 0; return; }                 // an unfilled slot (the call fails: a point outside the image)
+    const int cell = ((int)((unsigned)me.x >> 16) >> shift) * gw + ((me.x & 0xffff) >> shift);
+    bool repeat = false;
+    for (unsigned j = cell_start[cell]; j < cell_start[cell + 1]; ++j) {
+        const int2 o = binned[j];
+        // compares against the indices as first written: dead[] is applied by the next kernel, not here
+        repeat = repeat || (o.x == me.x && o.y < me.y);
+    }
+    dead[i] = repeat ? 1 : 0;
+}
+
+__global__ void apply_repeats_kernel(int n, int2 *__restrict__ binned, const int *__restrict__ dead) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && dead[i]) binned[i].y = -1;
+}
+
+// ---- the ring of one point ----
+// A point is served by NW wavefronts whose lanes all hold the SAME winner so far.  For an edge (p, a) the candidates on the
+// searched side are ordered by where the centre of their circle through p and a lies on the bisector of p a, which is the
+// order of the quotient (|c|^2 - a.c) / |a x c| (coordinates relative to p): the nearby candidates are ranked by it in
+// double and the smallest becomes the winner.  Then every candidate is asked, 64 at a time, whether it beats the winner
+// under the exact test: a lane whose candidate does raises its hand, the first such candidate becomes the winner of all
+// lanes and the chunk is asked again, until no hand goes up.  The exact test runs in every lane at once or not at all,
+// and behind the enlarged-circle test it is rare; after the ranking it only settles ties and rounding.
+// MODE 0, the first pass: a wavefront per point of the binned list; the points of the 7 x 7 cells around it are gathered
+//         once into two registers per lane (more than 128 of them: left to the next pass).
+// MODE 1, for what the first pass left: the points of the window of half-width W are gathered once into LDS (more than
+//         WIDE_CAP of them: left to the next pass).
+// MODE 2, for what is left then: every point is a candidate.  The 7 x 7 cells around the point (in registers, as in
+//         mode 0) give the first winner; then, for 64 rows of cells at a time, every lane works out which columns of
+//         ITS row can hold a better candidate (inside the winner's circle, on the searched side of the line p a) and
+//         reads that row's bounds, and the wavefronts share out the candidates of all rows in chunks of 64; the NW
+//         wavefronts' winners meet in LDS.
+constexpr int WIDE_CAP = 1024;
+
+template <int NW, int MODE>
+__global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restrict__ binned, int n, const unsigned *__restrict__ cell_start, int shift,
+                                                            int gw, int gh, int W, const int *__restrict__ todo_in, int in_slot,
+                                                            int2 *__restrict__ lead_all, int *__restrict__ lead_count, int *__restrict__ todo_out,
+                                                            int *__restrict__ counters, int out_slot) {
+    __shared__ int2 win[NW];
+    __shared__ int win_d[NW];
+    __shared__ double win_k[NW];
+    __shared__ int2 wide[MODE == 1 ? WIDE_CAP : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_todo = MODE == 0 ? n : counters[in_slot];
+    const int2 none = make_int2(-1, -1);
+    for (int w = blockIdx.x; w < n_todo; w += gridDim.x) {
+        const int slot = MODE == 0 ? w : todo_in[w];
+        const int2 me = binned[slot];
+        if (MODE == 0 && me.y < 0) continue;                 // a repeated position (or an unfilled slot)
+        const DPt p = unpack(me);
+        int2 *lead = lead_all + (size_t)p.id * MAX_LEAD;
+        const int cx = p.x >> shift, cy = p.y >> shift;
+        // what the candidates guarantee: every point within `reach` pixels of p (no limit on a side where the window
+        // ends at the image border; -1: no limit at all)
+        int reach = -1;
+        if (MODE != 2) {
+            reach = 0x7fffffff;
+            if (cx - W > 0) reach = min(reach, p.x - ((cx - W) << shift));
+            if (cx + W + 1 < gw) reach = min(reach, ((cx + W + 1) << shift) - 1 - p.x);
+            if (cy - W > 0) reach = min(reach, p.y - ((cy - W) << shift));
+            if (cy + W + 1 < gh) reach = min(reach, ((cy + W + 1) << shift) - 1 - p.y);
+            if (reach == 0x7fffffff) reach = -1;
+        }
+        // the 7 x 7 cells around the point into registers (modes 0 and 2): the row bounds are read by independent loads
+        int2 c0 = none, c1 = none;
+        int n_near = 0;
+        bool overfull = false;
+        if (MODE != 1) {
+            const int xa = max(cx - 3, 0), xb = min(cx + 4, gw), ya = max(cy - 3, 0), yb = min(cy + 4, gh);
+            int rs[7], re[7];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const bool in = ya + r < yb;
+                rs[r] = in ? (int)cell_start[(ya + r) * gw + xa] : 0;
+                re[r] = in ? (int)cell_start[(ya + r) * gw + xb] : 0;
+            }
+            int j0 = -1, j1 = -1;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const int cnt = re[r] - rs[r], i0 = lane - n_near, i1 = lane + 64 - n_near;
+                if (i0 >= 0 && i0 < cnt) j0 = rs[r] + i0;
+                if (i1 >= 0 && i1 < cnt) j1 = rs[r] + i1;
+                n_near += cnt;
+            }
+            if (j0 >= 0) c0 = binned[j0];
+            if (j1 >= 0) c1 = binned[j1];
+            if (MODE == 0) overfull = n_near > 128;
+        }
+        // the window of half-width W into LDS (mode 1): lane r reads the bounds of row r of the window
+        int n_wide = 0;
+        if (MODE == 1) {
+            const int xa = max(cx - W, 0), xb = min(cx + W + 1, gw), ya = max(cy - W, 0), yb = min(cy + W + 1, gh);
+            int s = 0, cnt = 0;
+            if (ya + lane < yb) { s = (int)cell_start[(ya + lane) * gw + xa]; cnt = (int)cell_start[(ya + lane) * gw + xb] - s; }
+            int incl = cnt;                                   // running total over the rows
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            n_wide = __shfl(incl, 63, 64);
+            overfull = n_wide > WIDE_CAP || yb - ya > 64;
+            if (!overfull) {
+                __syncthreads();                              // (one wavefront per workgroup in this mode: the last point's reads are done)
+                for (int r = 0; r < yb - ya; ++r) {
+                    const int rs = __shfl(s, r, 64), rc = __shfl(cnt, r, 64), at = __shfl(incl - cnt, r, 64);
+                    for (int i = lane; i < rc; i += 64) wide[at + i] = binned[rs + i];
+                }
+                __syncthreads();
+            }
+        }
+        // near(f): f(candidate or none) for every lane of every chunk of the candidates held on chip
+        auto near = [&](auto f) {
+            if (MODE == 1) {
+                for (int base = 0; base < n_wide; base += 64) f(base + lane < n_wide ? wide[base + lane] : none);
+                return;
+            }
+            f(c0);
+            if (n_near > 64) f(c1);
+        };
+        // far(f, cols): mode 2 only, f(candidate or none) for every lane of every chunk this wavefront takes of the binned
+        // list; cols(y0, y1, x0, x1) narrows the pixel columns [x0, x1] worth reading in the pixel rows y0..y1 (x0 > x1: none)
+        auto far = [&](auto f, auto cols) {
+            if (MODE != 2) return;
+            if (n_near > 128) {                               // (rare: more nearby points than the registers hold; every wavefront reads them)
+                const int xa = max(cx - 3, 0), xb = min(cx + 4, gw), ya = max(cy - 3, 0), yb = min(cy + 4, gh);
+                for (int y = ya; y < yb; ++y) {
+                    const unsigned s = cell_start[y * gw + xa], e = cell_start[y * gw + xb];
+                    for (unsigned base = s; base < e; base += 64u) f(base + lane < e ? binned[base + lane] : none);
+                }
+            }
+            for (int g = 0; g < gh; g += 64) {
+                const int y = g + lane;
+                int s = 0, cnt = 0;
+                if (y < gh) {
+                    double x0 = 0.0, x1 = (double)((gw << shift) - 1);
+                    cols((double)(y << shift), (double)(((y + 1) << shift) - 1), x0, x1);
+                    if (x0 <= x1) {
+                        const int xa = (int)x0 >> shift, xb = min(((int)x1 >> shift) + 1, gw);
+                        s = (int)cell_start[y * gw + xa];
+                        cnt = (int)cell_start[y * gw + xb] - s;
+                    }
+                }
+                int incl = cnt;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const int total = __shfl(incl, 63, 64), at = incl - cnt;
+                for (int base = 64 * wave; base < total; base += 256 * NW) {          // four loads in flight
+                    int2 c[4];
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = base + 64 * NW * u + lane;
+                        c[u] = none;
+                        if (base + 64 * NW * u < total) {                              // (uniform: the shuffles below need every lane)
+                            int lo = 0, hi = 63;                                        // the last row that starts at or before idx
+                            for (int it = 0; it < 6; ++it) {
+                                const int mid = (lo + hi + 1) >> 1;
+                                if (__shfl(at, mid, 64) <= idx) lo = mid; else hi = mid - 1;
+                            }
+                            const int rs = __shfl(s, lo, 64), ra = __shfl(at, lo, 64);
+                            if (idx < total) c[u] = binned[rs + idx - ra];
+                        }
+                    }
+                    for (int u = 0; u < 4; ++u)
+                        if (base + 64 * NW * u < total) f(c[u]);
+                }
+            }
+        };
+        // columns of the disc around (mx, my) of radius r within the pixel rows y0..y1 (doubles: r may be huge)
+        auto disc_cols = [&](double mx, double my, double r, double y0, double y1, double &x0, double &x1) {
+            const double d = my < y0 ? y0 - my : (my > y1 ? my - y1 : 0.0);
+            if (d > r) { x0 = 1.0; x1 = 0.0; return; }
+            const double half = sqrt(r * r - d * d) + 1.0;
+            x0 = fmax(x0, mx - half); x1 = fmin(x1, mx + half);
+        };
+        // nearest neighbour (ties: the smaller index, so that every wavefront agrees)
+        int bd = 0x7fffffff; int2 bc = none;
+        auto nearer = [&](int od, int2 oc) { if (oc.y >= 0 && (od < bd || (od == bd && oc.y < bc.y))) { bd = od; bc = oc; } };
+        auto by_distance = [&](int2 c) {
+            if (c.y < 0 || c.x == me.x) return;
+            const int dx = (c.x & 0xffff) - p.x, dy = (int)((unsigned)c.x >> 16) - p.y;
+            nearer(dx * dx + dy * dy, c);
+        };
+        near(by_distance);
+        for (int o = 32; o; o >>= 1) nearer(__shfl_xor(bd, o, 64), make_int2(__shfl_xor(bc.x, o, 64), __shfl_xor(bc.y, o, 64)));
+        if (MODE == 2) {
+            const double r_near = bd == 0x7fffffff ? 1e30 : sqrt((double)bd) + 1.0;     // a nearer point lies within the nearest found nearby
+            far(by_distance, [&](double y0, double y1, double &x0, double &x1) { disc_cols((double)p.x, (double)p.y, r_near, y0, y1, x0, x1); });
+            for (int o = 32; o; o >>= 1) nearer(__shfl_xor(bd, o, 64), make_int2(__shfl_xor(bc.x, o, 64), __shfl_xor(bc.y, o, 64)));
+            if (NW > 1) {
+                __syncthreads();
+                if (lane == 0) { win[wave] = bc; win_d[wave] = bd; }
+                __syncthreads();
+                for (int v = 0; v < NW; ++v) nearer(win_d[v], win[v]);
+            }
+        }
+        int n_lead = 0;
+        int verdict = 0;                                      // 0 done, -1 left over again, -2 beyond the limits
+        if (overfull) verdict = -1;
+        else if (bc.y < 0) verdict = reach < 0 ? 0 : -1;
+        else if (reach >= 0 && (long long)bd > (long long)reach * reach) verdict = -1;
+        else {
+            const int2 a0c = bc;
+            bool open = false;
+            for (int dir = 0; dir < 2 && verdict == 0; ++dir) {          // 0: counter-clockwise from a0; 1: clockwise, for an open ring
+                if (dir == 1) {
+                    if (!open) break;
+                    if (reach >= 0) { verdict = -1; break; }              // a hull point: only the whole point set can tell
+                }
+                DPt a = unpack(a0c);
+                int axy = a0c.x;
+                for (int step = 0;; ++step) {
+                    if (step >= MAX_RING) { verdict = -2; break; }
+                    DPt b; int2 bcc = none;
+                    Circle circ;
+                    // the nearby candidates ranked in double; when none of them lies on the searched side (mode 2), all that do
+                    const int ax = a.x - p.x, ay = a.y - p.y;
+                    const double A = dir == 0 ? (double)ay : (double)-ay, B = dir == 0 ? (double)ax : (double)-ax;
+                    // the searched side of the line p -> a in the pixel rows y0..y1: A (x - px) < B (y - py)
+                    auto side_cols = [&](double y0, double y1, double &x0, double &x1) {
+                        if (A > 0.0) x1 = fmin(x1, (double)p.x + fmax(B * (y0 - p.y), B * (y1 - p.y)) / A + 1.0);
+                        else if (A < 0.0) x0 = fmax(x0, (double)p.x + fmax(B * (y0 - p.y), B * (y1 - p.y)) / A - 1.0);   // (the larger numerator: A is negative)
+                        else if (B > 0.0 ? !(y1 > p.y) : !(y0 < p.y)) { x0 = 1.0; x1 = 0.0; }
+                    };
+                    double bk = 1e300; int2 bkc = none;
+                    auto rank = [&](int2 cc) {
+                        if (cc.y < 0 || cc.x == me.x || cc.x == axy) return;
+                        const int ccx = (cc.x & 0xffff) - p.x, ccy = (int)((unsigned)cc.x >> 16) - p.y;
+                        const int cr = ax * ccy - ay * ccx;
+                        if (dir == 0 ? cr <= 0 : cr >= 0) return;
+                        const double k = (double)(ccx * ccx + ccy * ccy - (ax * ccx + ay * ccy)) / fabs((double)cr);
+                        if (k < bk || (k == bk && cc.y > bkc.y)) { bk = k; bkc = cc; }
+                    };
+                    auto rank_meet = [&]() {
+                        for (int o = 32; o; o >>= 1) {
+                            const double ok = __shfl_xor(bk, o, 64);
+                            const int ox = __shfl_xor(bkc.x, o, 64), oy = __shfl_xor(bkc.y, o, 64);
+                            if (ok < bk || (ok == bk && oy > bkc.y)) { bk = ok; bkc = make_int2(ox, oy); }
+                        }
+                    };
+                    near(rank);
+                    rank_meet();
+                    if (MODE == 2 && bkc.y < 0) {
+                        far(rank, side_cols);
+                        rank_meet();
+                        if (NW > 1) {
+                            __syncthreads();
+                            if (lane == 0) { win[wave] = bkc; win_k[wave] = bk; }
+                            __syncthreads();
+                            for (int v = 0; v < NW; ++v)
+                                if (win_k[v] < bk || (win_k[v] == bk && win[v].y > bkc.y)) { bk = win_k[v]; bkc = win[v]; }
+                        }
+                    }
+                    if (bkc.y >= 0) { bcc = bkc; b = unpack(bcc); circ.set(p, a, b); }
+                    auto beats = [&](int2 cc) -> bool {                   // exact: does cc (on the searched side) beat the winner so far?
+                        if (cc.y < 0 || cc.x == me.x || cc.x == axy || cc.x == bcc.x) return false;
+                        if (bcc.y >= 0 && circ.outside(p, cc.x)) return false;
+                        const DPt c = unpack(cc);
+                        const int o = d_orient(p, a, c);
+                        if (dir == 0 ? o <= 0 : o >= 0) return false;
+                        return bcc.y < 0 || (dir == 0 ? d_in_circle(p, a, b, c) : d_in_circle(p, b, a, c)) > 0;
+                    };
+                    auto hands = [&](int2 cc) {
+                        for (;;) {
+                            const unsigned long long up = __ballot(beats(cc));
+                            if (!up) break;
+                            const int src = __ffsll((long long)up) - 1;
+                            bcc = make_int2(__shfl(cc.x, src, 64), __shfl(cc.y, src, 64));
+                            b = unpack(bcc);
+                            circ.set(p, a, b);
+                        }
+                    };
+                    near(hands);
+                    if (MODE == 2) {
+                        // the searched side of the line p -> a and, if there is a winner, its circle
+                        const bool has = bcc.y >= 0;
+                        const double mx = (double)p.x + circ.ox, my = (double)p.y + circ.oy, mr = has ? sqrt(circ.r2) : 0.0;
+                        far(hands, [&](double y0, double y1, double &x0, double &x1) {
+                            side_cols(y0, y1, x0, x1);
+                            if (x0 > x1) return;
+                            if (has) disc_cols(mx, my, mr, y0, y1, x0, x1);
+                        });
+                        if (NW > 1) {
+                            __syncthreads();
+                            if (lane == 0) win[wave] = bcc;
+                            __syncthreads();
+                            bcc = none;
+                            for (int v = 0; v < NW; ++v)
+                                if (beats(win[v])) { bcc = win[v]; b = unpack(bcc); circ.set(p, a, b); }
+                        }
+                    }
+                    if (bcc.y < 0) { if (dir == 0) open = true; break; }
+                    if (!circle_within(p, dir == 0 ? a : b, dir == 0 ? b : a, reach)) { verdict = -1; break; }
+                    const DPt u = dir == 0 ? a : b, v2 = dir == 0 ? b : a;     // triangle (p, u, v2), counter-clockwise
+                    if (p.id < u.id && p.id < v2.id) {
+                        if (n_lead >= MAX_LEAD) { verdict = -2; break; }
+                        if (threadIdx.x == 0) lead[n_lead] = make_int2(u.id, v2.id);
+                        ++n_lead;
+                    }
+                    a = b; axy = bcc.x;
+                    if (dir == 0 && axy == a0c.x) break;
+                }
+            }
+        }
+        if (threadIdx.x == 0) {
+            if (verdict == 0) lead_count[p.id] = n_lead;
+            else if (verdict == -1 && todo_out) todo_out[atomicAdd(&counters[out_slot], 1)] = slot;
+            else atomicOr(&counters[1], 1);
+        }
+        if (NW > 1 || MODE == 1) __syncthreads();
+    }
+}
+
+// Triangles in their final order: point by point, a point's triangles by their other two indices.
+__global__ void write_triangles_kernel(const int32_t *__restrict__ xy, int n, const int2 *__restrict__ lead_all, const int *__restrict__ lead_count,
+                                       const unsigned *__restrict__ lead_start, int capacity, int32_t *__restrict__ tri_idx, int32_t *__restrict__ tri_xy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cnt = lead_count[i];
+    const int2 *mine = lead_all + (size_t)i * MAX_LEAD;
+    unsigned slot = lead_start[i];
+    long long last = -1;
+    for (int r = 0; r < cnt; ++r, ++slot) {                 // selection in ascending (v1, v2): the pairs of one point are distinct
+        long long best = 0x7fffffffffffffffLL;
+        for (int j = 0; j < cnt; ++j) {
+            const long long key = ((long long)mine[j].x << 32) | (unsigned)mine[j].y;
+            if (key > last && key < best) best = key;
+        }
+        last = best;
+        if ((int)slot >= capacity) continue;
+        const int v1 = (int)(best >> 32), v2 = (int)(best & 0xffffffffLL);
+        if (tri_idx) { tri_idx[3 * (size_t)slot] = i; tri_idx[3 * (size_t)slot + 1] = v1; tri_idx[3 * (size_t)slot + 2] = v2; }
+        if (tri_xy) {
+            int32_t *o = tri_xy + 6 * (size_t)slot;
+            o[0] = xy[2 * i]; o[1] = xy[2 * i + 1]; o[2] = xy[2 * v1]; o[3] = xy[2 * v1 + 1]; o[4] = xy[2 * v2]; o[5] = xy[2 * v2 + 1];
+        }
+    }
+}
+
+template <class T>
+T *carve(char *&at, size_t count) {
+    T *p = (T *)at;
+    at += (count * sizeof(T) + 255) / 256 * 256;
+    return p;
+}
+
+}  // namespace
+
+// Device triangulation into the context's mesh block.  On success *tri_xy_out (corner coordinates, six per triangle) and
+// *tri_idx_out (index triples) point into that block, *n_tri is the number of triangles, and the block has room for the
+// planes behind them (*abc_out).  Returns SVX_ERR_UNSUPPORTED (no message change) when the point set is one the device
+// form does not take (a ring beyond its limits): the caller then uses the host triangulation.
+int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int rows, int cols, int32_t **tri_xy_out, int32_t **tri_idx_out,
+                              float **abc_out, int *n_tri) {
+    *n_tri = 0;
+    if (n < 3) return SVX_OK;
+    if (rows > 8192 || cols > 8192) return SVX_ERR_UNSUPPORTED;
+    // cells of about one point each: side 2^shift nearest the square root of the area per point, 4 .. 64 pixels
+    int shift = 2;
+    while (shift < 6 && (double)(1 << shift) * (1 << shift) * 2.0 < (double)rows * cols / n) ++shift;
+    const int gw = ((cols - 1) >> shift) + 1, gh = ((rows - 1) >> shift) + 1, n_cells = gw * gh;
+    const int W1 = 3, W2 = 10;                     // half-widths, in cells, of the two windowed passes
+    const size_t max_tri = 2 * (size_t)n;
+    size_t bytes = 0;
+    {
+        char *at = nullptr;
+        carve<int32_t>(at, 6 * max_tri); carve<int32_t>(at, 3 * max_tri); carve<float>(at, 3 * max_tri);
+        carve<unsigned>(at, 2 * (size_t)n_cells + 2); carve<int2>(at, n); carve<int>(at, n); carve<int>(at, n); carve<int>(at, n);
+        carve<unsigned>(at, (size_t)n + 1); carve<int>(at, (size_t)n + 1); carve<int2>(at, (size_t)n * MAX_LEAD); carve<int>(at, 4);
+        bytes = (size_t)(at - (char *)nullptr);
+    }
+    int rc = svx_block_reserve(ctx, &ctx->tri, &ctx->tri_bytes, bytes, "mesh on the device");
+    if (rc) return rc;
+    char *at = (char *)ctx->tri;
+    int32_t *tri_xy = carve<int32_t>(at, 6 * max_tri);
+    int32_t *tri_idx = carve<int32_t>(at, 3 * max_tri);
+    float *abc = carve<float>(at, 3 * max_tri);
+    unsigned *cell_start = carve<unsigned>(at, 2 * (size_t)n_cells + 2);   // counts, scanned in place; then the fill counters
+    unsigned *cell_fill = cell_start + n_cells + 1;
+    int2 *binned = carve<int2>(at, n);
+    int *dead = carve<int>(at, n);
+    int *todo = carve<int>(at, n);
+    int *todo2 = carve<int>(at, n);
+    unsigned *lead_start = carve<unsigned>(at, (size_t)n + 1);
+    int *lead_count = carve<int>(at, (size_t)n + 1);
+    int2 *lead_all = carve<int2>(at, (size_t)n * MAX_LEAD);
+    int *counters = carve<int>(at, 4);        // [0] points left by the first pass, [1] limits exceeded, [2] point outside the image, [3] points left by the second pass
+    hipStream_t st = ctx->stream;
+    const unsigned nb = svx_cdiv(n, 256);
+    SVX_HIP(ctx, hipMemsetAsync(cell_start, 0, (2 * (size_t)n_cells + 2) * sizeof(unsigned), st));
+    SVX_HIP(ctx, hipMemsetAsync(lead_count, 0, ((size_t)n + 1) * sizeof(int), st));
+    SVX_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+    SVX_HIP(ctx, hipMemsetAsync(binned, 0xff, (size_t)n * sizeof(int2), st));
+    int h_counters[4];
+    cell_count_kernel<<<nb, 256, 0, st>>>(pts_xy, n, rows, cols, shift, gw, cell_start, counters);
+    SVX_LAUNCH_CHECK(ctx, "cell_count_kernel");
+    scan16_kernel<<<1, 1024, 0, st>>>(cell_start, n_cells);
+    SVX_LAUNCH_CHECK(ctx, "scan16_kernel");
+    cell_fill_kernel<<<nb, 256, 0, st>>>(pts_xy, n, rows, cols, shift, gw, cell_start, cell_fill, binned);
+    SVX_LAUNCH_CHECK(ctx, "cell_fill_kernel");
+    mark_repeats_kernel<<<nb, 256, 0, st>>>(n, shift, gw, cell_start, binned, dead);
+    SVX_LAUNCH_CHECK(ctx, "mark_repeats_kernel");
+    apply_repeats_kernel<<<nb, 256, 0, st>>>(n, binned, dead);
+    SVX_LAUNCH_CHECK(ctx, "apply_repeats_kernel");
+    ring_wave_kernel<1, 0><<<std::min(n, 65536), 64, 0, st>>>(binned, n, cell_start, shift, gw, gh, W1, nullptr, 0, lead_all, lead_count, todo, counters, 0);
+    SVX_LAUNCH_CHECK(ctx, "ring_wave_kernel");
+    ring_wave_kernel<1, 1><<<std::min(n, 8192), 64, 0, st>>>(binned, n, cell_start, shift, gw, gh, W2, todo, 0, lead_all, lead_count, todo2, counters, 3);
+    SVX_LAUNCH_CHECK(ctx, "ring_wave_kernel");
+    ring_wave_kernel<8, 2><<<std::min(n, 2048), 512, 0, st>>>(binned, n, cell_start, shift, gw, gh, -1, todo2, 3, lead_all, lead_count, nullptr, counters, 0);
+    SVX_LAUNCH_CHECK(ctx, "ring_wave_kernel");
+    SVX_HIP(ctx, hipMemcpyAsync(lead_start, lead_count, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
+    scan16_kernel<<<1, 1024, 0, st>>>(lead_start, n);
+    SVX_LAUNCH_CHECK(ctx, "scan16_kernel");
+    write_triangles_kernel<<<nb, 256, 0, st>>>(pts_xy, n, lead_all, lead_count, lead_start, (int)max_tri, tri_idx, tri_xy);
+    SVX_LAUNCH_CHECK(ctx, "write_triangles_kernel");
+    unsigned total = 0;
+    SVX_HIP(ctx, hipMemcpyAsync(&total, lead_start + n, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    SVX_HIP(ctx, hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, st));
+    SVX_HIP(ctx, hipStreamSynchronize(st));
+    if (h_counters[2]) return svx_fail(ctx, SVX_ERR_INVALID_ARG, "mesh on the device: support point outside the image");
+    if (h_counters[1] || total > max_tri) return SVX_ERR_UNSUPPORTED;
+    ctx->mesh_left_over = h_counters[3];
+    ctx->mesh_left_first = h_counters[0];
+    *n_tri = (int)total;
+    *tri_xy_out = tri_xy;
+    *tri_idx_out = tri_idx;
+    *abc_out = abc;
+    return SVX_OK;
+}
+
+SVX_API int svx_mesh_device_stats(const svx_ctx *ctx, int *left_by_first_pass, int *left_by_second_pass) {
+    if (!ctx) return SVX_ERR_INVALID_ARG;
+    if (left_by_first_pass) *left_by_first_pass = ctx->mesh_left_first;
+    if (left_by_second_pass) *left_by_second_pass = ctx->mesh_left_over;
+    return SVX_OK;
+}
+
+SVX_API int svx_delaunay_device(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, int rows, int cols, int32_t *tri_idx, int capacity, int *n_tri_host) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, n_pts >= 0 && capacity >= 0 && n_tri_host, SVX_ERR_INVALID_ARG, "svx_delaunay_device: bad count or null result");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_delaunay_device: empty image");
+    SVX_REQUIRE(ctx, (n_pts == 0 || pts_xy) && (capacity == 0 || tri_idx), SVX_ERR_INVALID_ARG, "svx_delaunay_device: null pointer");
+    int32_t *d_xy = nullptr, *d_idx = nullptr;
+    float *d_abc = nullptr;
+    rc = svx_mesh_device_triangles(ctx, pts_xy, n_pts, rows, cols, &d_xy, &d_idx, &d_abc, n_tri_host);
+    if (rc == SVX_ERR_UNSUPPORTED)
+        return svx_fail(ctx, rc, "svx_delaunay_device: frames beyond 8192 x 8192 or a point with more than %d triangles around it: use svx_delaunay", MAX_RING);
+    if (rc) return rc;
+    const int m = std::min(*n_tri_host, capacity);
+    if (m) SVX_HIP(ctx, hipMemcpyAsync(tri_idx, d_idx, (size_t)m * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return SVX_OK;
+}
+
+SVX_API int svx_mesh_plane_prior_device(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float *disparities, int rows, int cols, float *prior,
+                                        int *n_tri_out) {
+    int rc = svx_enter(ctx);
+    if (rc) return rc;
+    SVX_REQUIRE(ctx, n_pts >= 0, SVX_ERR_INVALID_ARG, "svx_mesh_plane_prior_device: negative point count");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_mesh_plane_prior_device: empty image");
+    SVX_REQUIRE(ctx, disparities && prior && (n_pts == 0 || pts_xy), SVX_ERR_INVALID_ARG, "svx_mesh_plane_prior_device: null pointer");
+    int32_t *d_xy = nullptr, *d_idx = nullptr;
+    float *d_abc = nullptr;
+    int nt = 0;
+    rc = svx_mesh_device_triangles(ctx, pts_xy, n_pts, rows, cols, &d_xy, &d_idx, &d_abc, &nt);
+    if (rc == SVX_ERR_UNSUPPORTED) {                     // the host triangulation takes every point set
+        std::vector<int32_t> h(2 * (size_t)n_pts);
+        SVX_HIP(ctx, hipMemcpyAsync(h.data(), pts_xy, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return svx_mesh_plane_prior(ctx, h.data(), n_pts, disparities, rows, cols, prior, n_tri_out);
+    }
+    if (rc) return rc;
+    if (n_tri_out) *n_tri_out = nt;
+    if (nt == 0) return SVX_OK;
+    rc = svx_plane_fit(ctx, d_xy, nt, disparities, rows, cols, d_abc);
+    if (!rc) rc = svx_plane_prior_raster(ctx, d_xy, d_abc, nt, rows, cols, prior);
+    return rc;
+}

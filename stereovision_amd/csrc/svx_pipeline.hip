@@ -92,7 +92,7 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     // laid out twice (measure, then place)
     uint8_t *L, *Rr, *La, *Ra, *grad;
     uint32_t *cL, *cR;
-    int32_t *pts, *kpl, *kpr, *conf_x, *conf_y, *inv_x, *inv_y, *rs_xy, *stage_xy;
+    int32_t *pts, *kpl, *kpr, *conf_x, *conf_y, *inv_x, *inv_y, *rs_xy, *stage_xy, *sup_dev;
     float *respl, *respr, *disparities, *final_disp, *conf_d, *rs_d, *stage_d;
     int8_t *costs, *final_costs, *conf_c, *inv_c;
     uint8_t *rs_valid;
@@ -109,6 +109,7 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         conf_c = a.take<int8_t>(cells_needed); inv_c = a.take<int8_t>(cells_needed);
         rs_xy = a.take<int32_t>(4 * cells_needed); rs_d = a.take<float>(2 * cells_needed); rs_valid = a.take<uint8_t>(2 * cells_needed);
         stage_xy = a.take<int32_t>(2 * n); stage_d = a.take<float>(n);      // host-made point lists (at most one point a pixel)
+        sup_dev = a.take<int32_t>(2 * n);                                   // the support-point list, for the triangulation on the device
     };
     Arena measure;
     layout(measure);
@@ -214,15 +215,31 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         ~MeshHolder() { svx_mesh_destroy(m); }
     } mesh;
     size_t in_mesh = 0;                      // support points (pairs) already handed to the mesh
-    if (prm->recordFullDisp && prm->nIters > 0 && svx_mesh_create(&mesh.m) != SVX_OK) return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: mesh");
+    // By default the triangulation runs on the device, from the whole list each time (the mesh is a function of the point
+    // list alone, so this gives the triangles the growing host mesh would hold); the host only appends the new points.
+    const bool mesh_on_device = svx_opt(ctx, SVX_OPT_MESH_ON_DEVICE) != 0 && R <= 8192 && Cc <= 8192;
+    if (!mesh_on_device && prm->recordFullDisp && prm->nIters > 0 && svx_mesh_create(&mesh.m) != SVX_OK)
+        return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: mesh");
     for (int iter = 1; iter <= prm->nIters; ++iter) {                                                   // .cpp:451
         // plane table and interpolation of the prior over the whole frame (.cpp:454-466, :532-554)
         if (prm->recordFullDisp) {
             int n_tri = 0;
-            if (svx_mesh_insert(mesh.m, sup.data() + in_mesh, (int)((sup.size() - in_mesh) / 2)) != SVX_OK)
-                return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "svx_high_perf_stereo: mesh insertion failed");
-            in_mesh = sup.size();
-            SVX_TRY(svx_mesh_prior(ctx, mesh.m, disparities, R, Cc, disparities, &n_tri));
+            if (mesh_on_device) {
+                if (sup.size() > in_mesh) {
+                    void *pin;
+                    SVX_TRY(svx_pinned_reserve(ctx, (sup.size() - in_mesh) * sizeof(int32_t), &pin));
+                    memcpy(pin, sup.data() + in_mesh, (sup.size() - in_mesh) * sizeof(int32_t));
+                    SVX_HIP(ctx, hipMemcpyAsync(sup_dev + in_mesh, pin, (sup.size() - in_mesh) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+                    SVX_TRY(svx_pinned_mark_read(ctx));
+                    in_mesh = sup.size();
+                }
+                SVX_TRY(svx_mesh_plane_prior_device(ctx, sup_dev, (int)(sup.size() / 2), disparities, R, Cc, disparities, &n_tri));
+            } else {
+                if (svx_mesh_insert(mesh.m, sup.data() + in_mesh, (int)((sup.size() - in_mesh) / 2)) != SVX_OK)
+                    return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "svx_high_perf_stereo: mesh insertion failed");
+                in_mesh = sup.size();
+                SVX_TRY(svx_mesh_prior(ctx, mesh.m, disparities, R, Cc, disparities, &n_tri));
+            }
         }
         clk.mark(6);
         SVX_HIP(ctx, hipMemsetAsync(costs, t_high & 0xff, n, ctx->stream));                             // .cpp:573
