@@ -347,8 +347,9 @@ int svx_delaunay(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, int32_t *t
  * triangles around one point (or 32 led by one point): svx_delaunay takes those.
  * svx_mesh_plane_prior_device is svx_mesh_plane_prior with the points on the device and the triangulation done there
  * (it falls back to the host triangulation by itself where svx_delaunay_device would refuse).
- * svx_mesh_device_stats: how many points of the context's last device triangulation needed a second look at a wider
- * neighbourhood, and how many the pass over all points (a tuning aid; either pointer may be NULL). */
+ * svx_mesh_device_stats: how many points of the context's last device triangulation needed the second pass (a wider
+ * neighbourhood and, where that cannot tell, all points); the second number is always 0 (a tuning aid; either pointer
+ * may be NULL). */
 int svx_delaunay_device(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, int rows, int cols, int32_t *tri_idx, int capacity, int *n_tri_host);
 int svx_mesh_plane_prior_device(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float *disparities, int rows, int cols,
                                 float *prior, int *n_tri_out);

@@ -585,12 +585,8 @@ class Context:
         self._call("svx_delaunay_device", _dptr(pts_xy), n_pts, rows, cols, _dptr(tri), tri.shape[0], C.byref(n))
         return tri[:n.value]
 
-    def mesh_device_left_over(self):
-        """Points of the last device triangulation that needed the pass over all points."""
-        return self.mesh_device_stats()[1]
-
     def mesh_device_stats(self):
-        """(points left by the first pass, points left by the second pass) of the last device triangulation."""
+        """(points left to the second pass, 0) of the last device triangulation."""
         a, b = _i(0), _i(0)
         self._call("svx_mesh_device_stats", C.byref(a), C.byref(b))
         return a.value, b.value

@@ -76,35 +76,47 @@ struct Circle {
     }
 };
 
-// In-place exclusive scan of v[0..n) by one workgroup, sixteen consecutive values per thread and round; v[n] receives the total.
-__global__ __launch_bounds__(1024) void scan16_kernel(unsigned *__restrict__ v, int n) {
-    __shared__ unsigned wave_tot[16];
-    __shared__ unsigned carry;
+// In-place exclusive scan of v[0..n) by one workgroup, four consecutive values per thread and round (one 16-byte
+// load a lane); v[n] receives the total.  v must be 16-byte aligned.
+__global__ __launch_bounds__(1024) void scan4_kernel(unsigned *__restrict__ v, int n) {
+    __shared__ unsigned wave_tot[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 16384) {
-        const int i0 = base + 16 * (int)threadIdx.x;
-        unsigned x[16];
-        unsigned sum = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { x[k] = i0 + k < n ? v[i0 + k] : 0u; sum += x[k]; }
+    unsigned carry = 0;
+    int buf = 0;
+    for (int base = 0; base < n; base += 4096, buf ^= 1) {
+        const int i0 = base + 4 * (int)threadIdx.x;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (i0 + 3 < n) x = *(const uint4 *)(v + i0);
+        else {
+            if (i0 < n) x.x = v[i0];
+            if (i0 + 1 < n) x.y = v[i0 + 1];
+            if (i0 + 2 < n) x.z = v[i0 + 2];
+        }
+        const unsigned sum = x.x + x.y + x.z + x.w;
         unsigned incl = sum;                              // inclusive scan of the threads' sums inside the wavefront
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned t = __shfl_up(incl, o, 64);
             if (lane >= o) incl += t;
         }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        unsigned before = carry;
-        for (int w = 0; w < wave; ++w) before += wave_tot[w];
-        unsigned run = before + incl - sum;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { if (i0 + k < n) v[i0 + k] = run; run += x[k]; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = before + incl;
-        __syncthreads();
+        if (lane == 63) wave_tot[buf][wave] = incl;
+        __syncthreads();                                  // (the buffers alternate, so one meeting a round is enough)
+        unsigned before = carry, all = 0;
+        for (int w = 0; w < 16; ++w) {
+            const unsigned t = wave_tot[buf][w];
+            before += w < wave ? t : 0u;
+            all += t;
+        }
+        const unsigned e0 = before + incl - sum;
+        const uint4 out = make_uint4(e0, e0 + x.x, e0 + x.x + x.y, e0 + x.x + x.y + x.z);
+        if (i0 + 3 < n) *(uint4 *)(v + i0) = out;
+        else {
+            if (i0 < n) v[i0] = out.x;
+            if (i0 + 1 < n) v[i0 + 1] = out.y;
+            if (i0 + 2 < n) v[i0 + 2] = out.z;
+        }
+        carry += all;
     }
+    __syncthreads();                                      // every thread has read what it scans before the total lands behind it
     if (threadIdx.x == 0) v[n] = carry;
 }
 
@@ -159,14 +171,13 @@ __global__ void apply_repeats_kernel(int n, int2 *__restrict__ binned, const int
 // lanes and the chunk is asked again, until no hand goes up.  The exact test runs in every lane at once or not at all,
 // and behind the enlarged-circle test it is rare; after the ranking it only settles ties and rounding.
 // MODE 0, the first pass: a wavefront per point of the binned list; the points of the 7 x 7 cells around it are gathered
-//         once into two registers per lane (more than 128 of them: left to the next pass).
+//         once into two registers per lane (more than 128 of them: left to the second pass).
 // MODE 1, for what the first pass left: the points of the window of half-width W are gathered once into LDS (more than
-//         WIDE_CAP of them: left to the next pass).
-// MODE 2, for what is left then: every point is a candidate.  The 7 x 7 cells around the point (in registers, as in
-//         mode 0) give the first winner; then, for 64 rows of cells at a time, every lane works out which columns of
-//         ITS row can hold a better candidate (inside the winner's circle, on the searched side of the line p a) and
-//         reads that row's bounds, and the wavefronts share out the candidates of all rows in chunks of 64; the NW
-//         wavefronts' winners meet in LDS.
+//         WIDE_CAP of them: none are, and everything comes from the binned list) and give the first winner of a step.
+//         A winner whose circle stays within what the window guarantees is final; otherwise every point is a candidate:
+//         for 128 rows of cells at a time, every lane works out which columns of ITS two rows can hold a better
+//         candidate (inside the winner's circle, on the searched side of the line p a) and reads those rows' bounds,
+//         and the NW wavefronts share out the candidates of all rows in chunks of 64; their winners meet in LDS.
 constexpr int WIDE_CAP = 1024;
 
 template <int NW, int MODE>
@@ -190,20 +201,17 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
         const int cx = p.x >> shift, cy = p.y >> shift;
         // what the candidates guarantee: every point within `reach` pixels of p (no limit on a side where the window
         // ends at the image border; -1: no limit at all)
-        int reach = -1;
-        if (MODE != 2) {
-            reach = 0x7fffffff;
-            if (cx - W > 0) reach = min(reach, p.x - ((cx - W) << shift));
-            if (cx + W + 1 < gw) reach = min(reach, ((cx + W + 1) << shift) - 1 - p.x);
-            if (cy - W > 0) reach = min(reach, p.y - ((cy - W) << shift));
-            if (cy + W + 1 < gh) reach = min(reach, ((cy + W + 1) << shift) - 1 - p.y);
-            if (reach == 0x7fffffff) reach = -1;
-        }
-        // the 7 x 7 cells around the point into registers (modes 0 and 2): the row bounds are read by independent loads
+        int reach = 0x7fffffff;
+        if (cx - W > 0) reach = min(reach, p.x - ((cx - W) << shift));
+        if (cx + W + 1 < gw) reach = min(reach, ((cx + W + 1) << shift) - 1 - p.x);
+        if (cy - W > 0) reach = min(reach, p.y - ((cy - W) << shift));
+        if (cy + W + 1 < gh) reach = min(reach, ((cy + W + 1) << shift) - 1 - p.y);
+        if (reach == 0x7fffffff) reach = -1;
+        // the 7 x 7 cells around the point into registers (mode 0): the row bounds are read by independent loads
         int2 c0 = none, c1 = none;
         int n_near = 0;
         bool overfull = false;
-        if (MODE != 1) {
+        if (MODE == 0) {
             const int xa = max(cx - 3, 0), xb = min(cx + 4, gw), ya = max(cy - 3, 0), yb = min(cy + 4, gh);
             int rs[7], re[7];
 #pragma unroll
@@ -222,9 +230,9 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
             }
             if (j0 >= 0) c0 = binned[j0];
             if (j1 >= 0) c1 = binned[j1];
-            if (MODE == 0) overfull = n_near > 128;
+            overfull = n_near > 128;
         }
-        // the window of half-width W into LDS (mode 1): lane r reads the bounds of row r of the window
+        // the window of half-width W into LDS (mode 1): lane r reads the bounds of row r of the window (every wavefront, the same)
         int n_wide = 0;
         if (MODE == 1) {
             const int xa = max(cx - W, 0), xb = min(cx + W + 1, gw), ya = max(cy - W, 0), yb = min(cy + W + 1, gh);
@@ -236,15 +244,14 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                 if (lane >= o) incl += t;
             }
             n_wide = __shfl(incl, 63, 64);
-            overfull = n_wide > WIDE_CAP || yb - ya > 64;
-            if (!overfull) {
-                __syncthreads();                              // (one wavefront per workgroup in this mode: the last point's reads are done)
+            __syncthreads();                                  // the last point's reads of the LDS window are done
+            if (n_wide > WIDE_CAP || yb - ya > 64) { n_wide = 0; reach = 0; }      // too many: nothing held on chip, nothing guaranteed
+            else
                 for (int r = 0; r < yb - ya; ++r) {
                     const int rs = __shfl(s, r, 64), rc = __shfl(cnt, r, 64), at = __shfl(incl - cnt, r, 64);
-                    for (int i = lane; i < rc; i += 64) wide[at + i] = binned[rs + i];
+                    for (int i = threadIdx.x; i < rc; i += 64 * NW) wide[at + i] = binned[rs + i];
                 }
-                __syncthreads();
-            }
+            __syncthreads();
         }
         // near(f): f(candidate or none) for every lane of every chunk of the candidates held on chip
         auto near = [&](auto f) {
@@ -255,48 +262,47 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
             f(c0);
             if (n_near > 64) f(c1);
         };
-        // far(f, cols): mode 2 only, f(candidate or none) for every lane of every chunk this wavefront takes of the binned
+        // far(f, cols): mode 1 only, f(candidate or none) for every lane of every chunk this wavefront takes of the binned
         // list; cols(y0, y1, x0, x1) narrows the pixel columns [x0, x1] worth reading in the pixel rows y0..y1 (x0 > x1: none)
         auto far = [&](auto f, auto cols) {
-            if (MODE != 2) return;
-            if (n_near > 128) {                               // (rare: more nearby points than the registers hold; every wavefront reads them)
-                const int xa = max(cx - 3, 0), xb = min(cx + 4, gw), ya = max(cy - 3, 0), yb = min(cy + 4, gh);
-                for (int y = ya; y < yb; ++y) {
-                    const unsigned s = cell_start[y * gw + xa], e = cell_start[y * gw + xb];
-                    for (unsigned base = s; base < e; base += 64u) f(base + lane < e ? binned[base + lane] : none);
-                }
-            }
-            for (int g = 0; g < gh; g += 64) {
-                const int y = g + lane;
-                int s = 0, cnt = 0;
-                if (y < gh) {
-                    double x0 = 0.0, x1 = (double)((gw << shift) - 1);
-                    cols((double)(y << shift), (double)(((y + 1) << shift) - 1), x0, x1);
-                    if (x0 <= x1) {
-                        const int xa = (int)x0 >> shift, xb = min(((int)x1 >> shift) + 1, gw);
-                        s = (int)cell_start[y * gw + xa];
-                        cnt = (int)cell_start[y * gw + xb] - s;
+            if (MODE != 1) return;
+            for (int g = 0; g < gh; g += 128) {                // 128 rows of cells a round: two per lane, their loads in flight together
+                int s[2] = {0, 0}, cnt[2] = {0, 0};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int y = g + 64 * h + lane;
+                    if (y < gh) {
+                        double x0 = 0.0, x1 = (double)((gw << shift) - 1);
+                        cols((double)(y << shift), (double)(((y + 1) << shift) - 1), x0, x1);
+                        if (x0 <= x1) {
+                            const int xa = (int)x0 >> shift, xb = min(((int)x1 >> shift) + 1, gw);
+                            s[h] = (int)cell_start[y * gw + xa];
+                            cnt[h] = (int)cell_start[y * gw + xb] - s[h];
+                        }
                     }
                 }
-                int incl = cnt;
+                int incl0 = cnt[0], incl1 = cnt[1];
                 for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += t;
+                    const int t0 = __shfl_up(incl0, o, 64), t1 = __shfl_up(incl1, o, 64);
+                    if (lane >= o) { incl0 += t0; incl1 += t1; }
                 }
-                const int total = __shfl(incl, 63, 64), at = incl - cnt;
+                const int total0 = __shfl(incl0, 63, 64), total = total0 + __shfl(incl1, 63, 64);
+                const int at0 = incl0 - cnt[0], at1 = total0 + incl1 - cnt[1];          // where each row starts among the round's candidates
                 for (int base = 64 * wave; base < total; base += 256 * NW) {          // four loads in flight
                     int2 c[4];
                     for (int u = 0; u < 4; ++u) {
                         const int idx = base + 64 * NW * u + lane;
                         c[u] = none;
                         if (base + 64 * NW * u < total) {                              // (uniform: the shuffles below need every lane)
+                            const bool second = idx >= total0;
                             int lo = 0, hi = 63;                                        // the last row that starts at or before idx
                             for (int it = 0; it < 6; ++it) {
                                 const int mid = (lo + hi + 1) >> 1;
-                                if (__shfl(at, mid, 64) <= idx) lo = mid; else hi = mid - 1;
+                                const int m0 = __shfl(at0, mid, 64), m1 = __shfl(at1, mid, 64);
+                                if ((second ? m1 : m0) <= idx) lo = mid; else hi = mid - 1;
                             }
-                            const int rs = __shfl(s, lo, 64), ra = __shfl(at, lo, 64);
-                            if (idx < total) c[u] = binned[rs + idx - ra];
+                            const int rs0 = __shfl(s[0], lo, 64), rs1 = __shfl(s[1], lo, 64), ra0 = __shfl(at0, lo, 64), ra1 = __shfl(at1, lo, 64);
+                            if (idx < total) c[u] = binned[(second ? rs1 : rs0) + idx - (second ? ra1 : ra0)];
                         }
                     }
                     for (int u = 0; u < 4; ++u)
@@ -321,8 +327,8 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
         };
         near(by_distance);
         for (int o = 32; o; o >>= 1) nearer(__shfl_xor(bd, o, 64), make_int2(__shfl_xor(bc.x, o, 64), __shfl_xor(bc.y, o, 64)));
-        if (MODE == 2) {
-            const double r_near = bd == 0x7fffffff ? 1e30 : sqrt((double)bd) + 1.0;     // a nearer point lies within the nearest found nearby
+        if (MODE == 1 && !(bc.y >= 0 && (reach < 0 || (long long)bd <= (long long)reach * reach))) {
+            const double r_near = bd == 0x7fffffff ? 1e30 : sqrt((double)bd) + 1.0;     // a nearer point lies within the nearest found in the window
             far(by_distance, [&](double y0, double y1, double &x0, double &x1) { disc_cols((double)p.x, (double)p.y, r_near, y0, y1, x0, x1); });
             for (int o = 32; o; o >>= 1) nearer(__shfl_xor(bd, o, 64), make_int2(__shfl_xor(bc.x, o, 64), __shfl_xor(bc.y, o, 64)));
             if (NW > 1) {
@@ -335,15 +341,15 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
         int n_lead = 0;
         int verdict = 0;                                      // 0 done, -1 left over again, -2 beyond the limits
         if (overfull) verdict = -1;
-        else if (bc.y < 0) verdict = reach < 0 ? 0 : -1;
-        else if (reach >= 0 && (long long)bd > (long long)reach * reach) verdict = -1;
+        else if (bc.y < 0) verdict = (MODE == 1 || reach < 0) ? 0 : -1;          // (mode 1 has seen every point: there is no other)
+        else if (MODE == 0 && reach >= 0 && (long long)bd > (long long)reach * reach) verdict = -1;
         else {
             const int2 a0c = bc;
             bool open = false;
             for (int dir = 0; dir < 2 && verdict == 0; ++dir) {          // 0: counter-clockwise from a0; 1: clockwise, for an open ring
                 if (dir == 1) {
                     if (!open) break;
-                    if (reach >= 0) { verdict = -1; break; }              // a hull point: only the whole point set can tell
+                    if (MODE == 0 && reach >= 0) { verdict = -1; break; }  // a hull point: only the whole point set can tell
                 }
                 DPt a = unpack(a0c);
                 int axy = a0c.x;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                     };
                     near(rank);
                     rank_meet();
-                    if (MODE == 2 && bkc.y < 0) {
+                    if (MODE == 1 && bkc.y < 0) {
                         far(rank, side_cols);
                         rank_meet();
                         if (NW > 1) {
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                         }
                     };
                     near(hands);
-                    if (MODE == 2) {
+                    if (MODE == 1 && !(bcc.y >= 0 && circle_within(p, a, b, reach))) {
                         // the searched side of the line p -> a and, if there is a winner, its circle
                         const bool has = bcc.y >= 0;
                         const double mx = (double)p.x + circ.ox, my = (double)p.y + circ.oy, mr = has ? sqrt(circ.r2) : 0.0;
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                         }
                     }
                     if (bcc.y < 0) { if (dir == 0) open = true; break; }
-                    if (!circle_within(p, dir == 0 ? a : b, dir == 0 ? b : a, reach)) { verdict = -1; break; }
+                    if (MODE == 0 && !circle_within(p, a, b, reach)) { verdict = -1; break; }
                     const DPt u = dir == 0 ? a : b, v2 = dir == 0 ? b : a;     // triangle (p, u, v2), counter-clockwise
                     if (p.id < u.id && p.id < v2.id) {
                         if (n_lead >= MAX_LEAD) { verdict = -2; break; }
@@ -497,13 +503,13 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
     int shift = 2;
     while (shift < 6 && (double)(1 << shift) * (1 << shift) * 2.0 < (double)rows * cols / n) ++shift;
     const int gw = ((cols - 1) >> shift) + 1, gh = ((rows - 1) >> shift) + 1, n_cells = gw * gh;
-    const int W1 = 3, W2 = 10;                     // half-widths, in cells, of the two windowed passes
+    const int W1 = 3, W2 = 8;                     // half-widths, in cells, of the two windowed passes
     const size_t max_tri = 2 * (size_t)n;
     size_t bytes = 0;
     {
         char *at = nullptr;
         carve<int32_t>(at, 6 * max_tri); carve<int32_t>(at, 3 * max_tri); carve<float>(at, 3 * max_tri);
-        carve<unsigned>(at, 2 * (size_t)n_cells + 2); carve<int2>(at, n); carve<int>(at, n); carve<int>(at, n); carve<int>(at, n);
+        carve<unsigned>(at, 2 * (size_t)n_cells + 2); carve<int2>(at, n); carve<int>(at, n); carve<int>(at, n);
         carve<unsigned>(at, (size_t)n + 1); carve<int>(at, (size_t)n + 1); carve<int2>(at, (size_t)n * MAX_LEAD); carve<int>(at, 4);
         bytes = (size_t)(at - (char *)nullptr);
     }
@@ -518,11 +524,10 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
     int2 *binned = carve<int2>(at, n);
     int *dead = carve<int>(at, n);
     int *todo = carve<int>(at, n);
-    int *todo2 = carve<int>(at, n);
     unsigned *lead_start = carve<unsigned>(at, (size_t)n + 1);
     int *lead_count = carve<int>(at, (size_t)n + 1);
     int2 *lead_all = carve<int2>(at, (size_t)n * MAX_LEAD);
-    int *counters = carve<int>(at, 4);        // [0] points left by the first pass, [1] limits exceeded, [2] point outside the image, [3] points left by the second pass
+    int *counters = carve<int>(at, 4);        // [0] points left by the first pass, [1] limits exceeded, [2] point outside the image, [3] unused
     hipStream_t st = ctx->stream;
     const unsigned nb = svx_cdiv(n, 256);
     SVX_HIP(ctx, hipMemsetAsync(cell_start, 0, (2 * (size_t)n_cells + 2) * sizeof(unsigned), st));
@@ -532,8 +537,8 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
     int h_counters[4];
     cell_count_kernel<<<nb, 256, 0, st>>>(pts_xy, n, rows, cols, shift, gw, cell_start, counters);
     SVX_LAUNCH_CHECK(ctx, "cell_count_kernel");
-    scan16_kernel<<<1, 1024, 0, st>>>(cell_start, n_cells);
-    SVX_LAUNCH_CHECK(ctx, "scan16_kernel");
+    scan4_kernel<<<1, 1024, 0, st>>>(cell_start, n_cells);
+    SVX_LAUNCH_CHECK(ctx, "scan4_kernel");
     cell_fill_kernel<<<nb, 256, 0, st>>>(pts_xy, n, rows, cols, shift, gw, cell_start, cell_fill, binned);
     SVX_LAUNCH_CHECK(ctx, "cell_fill_kernel");
     mark_repeats_kernel<<<nb, 256, 0, st>>>(n, shift, gw, cell_start, binned, dead);
@@ -542,13 +547,11 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
     SVX_LAUNCH_CHECK(ctx, "apply_repeats_kernel");
     ring_wave_kernel<1, 0><<<std::min(n, 65536), 64, 0, st>>>(binned, n, cell_start, shift, gw, gh, W1, nullptr, 0, lead_all, lead_count, todo, counters, 0);
     SVX_LAUNCH_CHECK(ctx, "ring_wave_kernel");
-    ring_wave_kernel<1, 1><<<std::min(n, 8192), 64, 0, st>>>(binned, n, cell_start, shift, gw, gh, W2, todo, 0, lead_all, lead_count, todo2, counters, 3);
-    SVX_LAUNCH_CHECK(ctx, "ring_wave_kernel");
-    ring_wave_kernel<8, 2><<<std::min(n, 2048), 512, 0, st>>>(binned, n, cell_start, shift, gw, gh, -1, todo2, 3, lead_all, lead_count, nullptr, counters, 0);
+    ring_wave_kernel<2, 1><<<std::min(n, 8192), 128, 0, st>>>(binned, n, cell_start, shift, gw, gh, W2, todo, 0, lead_all, lead_count, nullptr, counters, 3);
     SVX_LAUNCH_CHECK(ctx, "ring_wave_kernel");
     SVX_HIP(ctx, hipMemcpyAsync(lead_start, lead_count, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
-    scan16_kernel<<<1, 1024, 0, st>>>(lead_start, n);
-    SVX_LAUNCH_CHECK(ctx, "scan16_kernel");
+    scan4_kernel<<<1, 1024, 0, st>>>(lead_start, n);
+    SVX_LAUNCH_CHECK(ctx, "scan4_kernel");
     write_triangles_kernel<<<nb, 256, 0, st>>>(pts_xy, n, lead_all, lead_count, lead_start, (int)max_tri, tri_idx, tri_xy);
     SVX_LAUNCH_CHECK(ctx, "write_triangles_kernel");
     unsigned total = 0;
@@ -557,7 +560,7 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
     SVX_HIP(ctx, hipStreamSynchronize(st));
     if (h_counters[2]) return svx_fail(ctx, SVX_ERR_INVALID_ARG, "mesh on the device: support point outside the image");
     if (h_counters[1] || total > max_tri) return SVX_ERR_UNSUPPORTED;
-    ctx->mesh_left_over = h_counters[3];
+    ctx->mesh_left_over = 0;
     ctx->mesh_left_first = h_counters[0];
     *n_tri = (int)total;
     *tri_xy_out = tri_xy;

@@ -70,7 +70,7 @@ def test_empty_areas_and_clusters(ctx):
     rng.shuffle(pts)
     got, want = both(ctx, pts, rows, cols)
     assert np.array_equal(got, want)
-    assert ctx.mesh_device_left_over() > 0
+    assert ctx.mesh_device_stats()[0] > 0
 
 
 @pytest.mark.parametrize("step", [1, 3, 4, 16, 17])

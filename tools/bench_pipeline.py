@@ -15,7 +15,26 @@ import stereovision_amd as S  # noqa: E402
 from stereovision_amd import synth  # noqa: E402
 
 
+def single(n_iters, frames=20):
+    """Only a stream of single-threaded frames (for a kernel trace): prints frames and wall time."""
+    rows, cols = 375, 1242
+    ctx = S.Context(0)
+    p = S.StereoParameters.reference_defaults(maxDisp=70, nIters=n_iters)
+    l, r = [torch.from_numpy(a).cuda() for a in synth.stereo_pair(rows, cols, 64, 0)[:2]]
+    out = torch.zeros((rows, cols), dtype=torch.float32, device="cuda")
+    ctx.high_perf_stereo(l, r, p, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        ctx.high_perf_stereo(l, r, p, out)
+    torch.cuda.synchronize()
+    print(json.dumps({"frames": frames + 1, "nIters": n_iters, "ms_per_frame": round((time.perf_counter() - t0) * 1e3 / frames, 3),
+                      "mesh_points_left_by_pass_1_and_2": ctx.mesh_device_stats()}))
+
+
 def main():
+    if "--single" in sys.argv:
+        return single(int(sys.argv[sys.argv.index("--single") + 1]))
     rows, cols = 375, 1242
     ctx = S.Context(0)
     for n_iters in (1, 2, 3):
