@@ -76,6 +76,9 @@ int svx_block_reserve(svx_ctx *ctx, void **block, size_t *block_bytes, size_t by
 int svx_enter(svx_ctx *ctx);
 int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int rows, int cols, int32_t **tri_xy_out, int32_t **tri_idx_out,
                               float **abc_out, int *n_tri);      // svx_mesh_dev.hip
+int svx_sparse_match_lists(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, const int32_t *left_xy,
+                           int n_left, const int32_t *right_xy, int n_right, int max_disparity, float y_tolerance, float uniqueness,
+                           int left_right_step, int *first_dev, int *cost_dev);      // svx_sparse.hip: device key-point lists in raster order
 int svx_static_scratch_locate(svx_ctx *ctx);   // svx_dense.hip: finds this device's copy of the fixed scratch array
 
 // Matrix-core form of the dense search on two-word descriptors (svx_dense_mx.hip).

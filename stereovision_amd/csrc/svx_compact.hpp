@@ -48,6 +48,50 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(unsigned *__restrict
     if (threadIdx.x == 0) line_count[n_lines] = carry;
 }
 
+// In-place exclusive scan of v[0..n) by one workgroup, four consecutive values per thread and round (one 16-byte
+// load a lane); v[n] receives the total.  v must be 16-byte aligned.
+__global__ __launch_bounds__(1024) void scan4_kernel(unsigned *__restrict__ v, int n) {
+    __shared__ unsigned wave_tot[2][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned carry = 0;
+    int buf = 0;
+    for (int base = 0; base < n; base += 4096, buf ^= 1) {
+        const int i0 = base + 4 * (int)threadIdx.x;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (i0 + 3 < n) x = *(const uint4 *)(v + i0);
+        else {
+            if (i0 < n) x.x = v[i0];
+            if (i0 + 1 < n) x.y = v[i0 + 1];
+            if (i0 + 2 < n) x.z = v[i0 + 2];
+        }
+        const unsigned sum = x.x + x.y + x.z + x.w;
+        unsigned incl = sum;                              // inclusive scan of the threads' sums inside the wavefront
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[buf][wave] = incl;
+        __syncthreads();                                  // (the buffers alternate, so one meeting a round is enough)
+        unsigned before = carry, all = 0;
+        for (int w = 0; w < 16; ++w) {
+            const unsigned t = wave_tot[buf][w];
+            before += w < wave ? t : 0u;
+            all += t;
+        }
+        const unsigned e0 = before + incl - sum;
+        const uint4 out = make_uint4(e0, e0 + x.x, e0 + x.x + x.y, e0 + x.x + x.y + x.z);
+        if (i0 + 3 < n) *(uint4 *)(v + i0) = out;
+        else {
+            if (i0 < n) v[i0] = out.x;
+            if (i0 + 1 < n) v[i0 + 1] = out.y;
+            if (i0 + 2 < n) v[i0 + 2] = out.z;
+        }
+        carry += all;
+    }
+    __syncthreads();                                      // every thread has read what it scans before the total lands behind it
+    if (threadIdx.x == 0) v[n] = carry;
+}
+
 template <class Pred, class Emit>
 __global__ __launch_bounds__(256) void compact_write_kernel(Pred pred, Emit emit, int rows, int cols,
                                                             const unsigned *__restrict__ line_off, unsigned capacity) {

@@ -1,8 +1,9 @@
 // highPerfStereo(): the support-point / plane-prior pipeline that calls the census path end to end
-// (highPerfStereo/highPerfStereoLib.cpp:177-645), as host glue over the libsvx entry points.  Every image
-// stays on the device; the host sees key points, matches, the support-point list and the occupancy grid,
-// as the reference's host code does.
+// (highPerfStereo/highPerfStereoLib.cpp:177-645), as host glue over the libsvx entry points.  Every image and
+// every list stays on the device (key points, matches, the support-point list, the mesh, the occupancy grid); the
+// host sees counts, and the computed points at the end.
 #include "svx_common.hpp"
+#include "svx_compact.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -26,6 +27,66 @@ __global__ void vertex_disparities_kernel(const int32_t *__restrict__ xy, int n,
         const long p = (long)xy[2 * i + 1] * cols + xy[2 * i];
         final_disp[p] = (float)(int)disparities[p];
     }
+}
+
+// The support points the sparse matcher yields, in the order of the left key-point list (highPerfStereoLib.cpp:434-445):
+// matched[i] = 1 when left feature i has a match; then, ranked by the scan of those flags, the point goes into the
+// support list, its disparity x_left - x_right (SparseMatch::disparity(), sparsematch.h:27-29) into the map, and its
+// pixel is marked as taken.  Key points are distinct pixels, so no position repeats here.
+__global__ void support_flags_kernel(const int *__restrict__ first, int nl, unsigned *__restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nl) flag[i] = first[i] != -1 ? 1u : 0u;
+}
+
+__global__ void support_emit_kernel(const int32_t *__restrict__ kl, const int32_t *__restrict__ kr, const int *__restrict__ first, int nl,
+                                    const unsigned *__restrict__ rank, int cols, int32_t *__restrict__ sup, float *__restrict__ disparities,
+                                    uint8_t *__restrict__ taken) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nl || first[i] == -1) return;
+    const int x = kl[2 * i], y = kl[2 * i + 1];
+    const unsigned k = rank[i];
+    sup[2 * k] = x; sup[2 * k + 1] = y;
+    disparities[(long)y * cols + x] = (float)x - (float)kr[2 * first[i]];
+    taken[(long)y * cols + x] = 1;
+}
+
+// The resampling step's points join the support list in slot order, a position that is taken already (by an earlier
+// support point or an earlier slot of this step) only once (highPerfStereoLib.cpp:141-175 inserts into a mesh that
+// ignores repeats): the smallest slot at a free pixel owns it.
+__global__ void resample_owner_kernel(const int32_t *__restrict__ xy, const uint8_t *__restrict__ valid, int n_slots, int cols,
+                                      const uint8_t *__restrict__ taken, int *__restrict__ owner) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots || !valid[s]) return;
+    const long p = (long)xy[2 * s + 1] * cols + xy[2 * s];
+    if (!taken[p]) atomicMin(&owner[p], s);
+}
+
+__global__ void resample_flags_kernel(const int32_t *__restrict__ xy, const uint8_t *__restrict__ valid, int n_slots, int cols,
+                                      const uint8_t *__restrict__ taken, const int *__restrict__ owner, unsigned *__restrict__ flag) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    unsigned f = 0;
+    if (valid[s]) {
+        const long p = (long)xy[2 * s + 1] * cols + xy[2 * s];
+        f = (!taken[p] && owner[p] == s) ? 1u : 0u;
+    }
+    flag[s] = f;
+}
+
+__global__ void resample_emit_kernel(const int32_t *__restrict__ xy, int n_slots, int cols, const unsigned *__restrict__ rank, int n_sup,
+                                     int32_t *__restrict__ sup, uint8_t *__restrict__ taken, int *__restrict__ owner) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots || rank[s + 1] == rank[s]) return;
+    const int x = xy[2 * s], y = xy[2 * s + 1];
+    const unsigned k = (unsigned)n_sup + rank[s];
+    sup[2 * k] = x; sup[2 * k + 1] = y;
+    taken[(long)y * cols + x] = 1;
+    owner[(long)y * cols + x] = 0x7fffffff;          // free again for the next step
+}
+
+__global__ void fill_int_kernel(int *__restrict__ v, long n, int value) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = value;
 }
 
 // Bump allocator over one device allocation (the context's workspace belongs to the entry points called below).
@@ -92,8 +153,11 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     // laid out twice (measure, then place)
     uint8_t *L, *Rr, *La, *Ra, *grad;
     uint32_t *cL, *cR;
-    int32_t *pts, *kpl, *kpr, *conf_x, *conf_y, *inv_x, *inv_y, *rs_xy, *stage_xy, *sup_dev;
-    float *respl, *respr, *disparities, *final_disp, *conf_d, *rs_d, *stage_d;
+    int32_t *pts, *kpl, *kpr, *conf_x, *conf_y, *inv_x, *inv_y, *rs_xy, *sup_dev;
+    int *m_first, *m_cost, *owner;
+    unsigned *rank;
+    uint8_t *taken;
+    float *respl, *respr, *disparities, *final_disp, *conf_d, *rs_d;
     int8_t *costs, *final_costs, *conf_c, *inv_c;
     uint8_t *rs_valid;
     auto layout = [&](Arena &a) {
@@ -108,8 +172,10 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         conf_d = a.take<float>(cells_needed);
         conf_c = a.take<int8_t>(cells_needed); inv_c = a.take<int8_t>(cells_needed);
         rs_xy = a.take<int32_t>(4 * cells_needed); rs_d = a.take<float>(2 * cells_needed); rs_valid = a.take<uint8_t>(2 * cells_needed);
-        stage_xy = a.take<int32_t>(2 * n); stage_d = a.take<float>(n);      // host-made point lists (at most one point a pixel)
-        sup_dev = a.take<int32_t>(2 * n);                                   // the support-point list, for the triangulation on the device
+        sup_dev = a.take<int32_t>(2 * n);                                   // the support-point list (at most one point a pixel)
+        m_first = a.take<int>(n); m_cost = a.take<int>(n);                  // the sparse matcher's records, one per left key point
+        rank = a.take<unsigned>(std::max(n, 2 * cells_needed) + 4);         // flags, scanned in place
+        taken = a.take<uint8_t>(n); owner = a.take<int>(n);                 // pixels that hold a support point / that a resampling slot claims
     };
     Arena measure;
     layout(measure);
@@ -160,84 +226,68 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     SVX_TRY(svx_census5x5_u8(ctx, Rr, cR, R, Cc, 1, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST));
 
     clk.mark(3);
-    // sparse matching of the key points (.cpp:354-355, :390)
-    std::vector<int32_t> hl(2 * (size_t)nl), hr(2 * (size_t)nr);
-    if (nl) SVX_HIP(ctx, hipMemcpyAsync(hl.data(), kpl, hl.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (nr) SVX_HIP(ctx, hipMemcpyAsync(hr.data(), kpr, hr.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<float> fl(hl.begin(), hl.end()), fr(hr.begin(), hr.end());
-    fl.push_back(0.f); fr.push_back(0.f);     // never read: keeps data() non-null for empty lists
-    std::vector<int32_t> ml(nl ? nl : 1), mr(nl ? nl : 1);
-    std::vector<int16_t> mc(nl ? nl : 1);
-    int n_rec = 0;
-    SVX_TRY(svx_sparse_match(ctx, cL, cR, R, Cc, fl.data(), nl, fr.data(), nr, prm->maxDisp, 1.0f, (float)prm->uniqueness, prm->leftRightStep,
-                             ml.data(), mr.data(), mc.data(), &n_rec));
+    // sparse matching of the key points (.cpp:354-355, :390): the detector's lists stay on the device, where they are in
+    // raster order already; the matcher's records never leave it either
+    if (nl && nr)
+        SVX_TRY(svx_sparse_match_lists(ctx, cL, cR, R, Cc, kpl, nl, kpr, nr, prm->maxDisp, 1.0f, (float)prm->uniqueness, prm->leftRightStep, m_first, m_cost));
 
     clk.mark(4);
-    // support points of the mesh, in insertion order, repeated positions dropped (.cpp:434-445)
-    std::vector<int32_t> sup;                 // x,y pairs
-    std::vector<float> sup_d;
-    std::vector<uint8_t> seen(n, 0);
-    auto insert_point = [&](int x, int y) {
-        uint8_t &s = seen[(size_t)y * Cc + x];
-        if (!s) { s = 1; sup.push_back(x); sup.push_back(y); }
-    };
-    std::vector<int32_t> sxy;
-    for (int i = 0; i < n_rec; ++i) {
-        if (mr[i] < 0) continue;
-        const int x = hl[2 * ml[i]], y = hl[2 * ml[i] + 1];
-        sxy.push_back(x); sxy.push_back(y);
-        sup_d.push_back((float)x - (float)hr[2 * mr[i]]);       // SparseMatch::disparity(), sparsematch.h:27-29
-        insert_point(x, y);
-    }
+    // support points of the mesh, in insertion order, repeated positions dropped (.cpp:434-445): a ranked write on the device
     SVX_HIP(ctx, hipMemsetAsync(disparities, 0, n * sizeof(float), ctx->stream));
-    auto upload_scatter = [&](const std::vector<int32_t> &xy, const std::vector<float> &d) -> int {
-        const int m = (int)d.size();
-        if (!m) return SVX_OK;
-        SVX_HIP(ctx, hipMemcpyAsync(stage_xy, xy.data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
-        SVX_HIP(ctx, hipMemcpyAsync(stage_d, d.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-        scatter_support_kernel<<<svx_cdiv(m, 256), 256, 0, ctx->stream>>>(stage_xy, stage_d, m, Cc, disparities);
-        SVX_LAUNCH_CHECK(ctx, "scatter_support_kernel");
-        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the host vectors go out of scope
+    SVX_HIP(ctx, hipMemsetAsync(taken, 0, n, ctx->stream));
+    int n_sup = 0;
+    auto read_total = [&](int n_flags, int *total) -> int {       // scans rank[0 .. n_flags) in place and brings the total to the host
+        scan4_kernel<<<1, 1024, 0, ctx->stream>>>(rank, n_flags);
+        SVX_LAUNCH_CHECK(ctx, "scan4_kernel");
+        unsigned t = 0;
+        SVX_HIP(ctx, hipMemcpyAsync(&t, rank + n_flags, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *total = (int)t;
         return SVX_OK;
     };
-    SVX_TRY(upload_scatter(sxy, sup_d));
+    if (nl && nr) {
+        support_flags_kernel<<<svx_cdiv(nl, 256), 256, 0, ctx->stream>>>(m_first, nl, rank);
+        SVX_LAUNCH_CHECK(ctx, "support_flags_kernel");
+        SVX_TRY(read_total(nl, &n_sup));
+        support_emit_kernel<<<svx_cdiv(nl, 256), 256, 0, ctx->stream>>>(kpl, kpr, m_first, nl, rank, Cc, sup_dev, disparities, taken);
+        SVX_LAUNCH_CHECK(ctx, "support_emit_kernel");
+    }
 
     // final maps: the caller's disparity map (input-sized, .cpp:190) restricted to the cropped frame; costs start at 25 (.cpp:448)
     SVX_HIP(ctx, hipMemcpy2DAsync(final_disp, (size_t)Cc * 4, disparity_map, (size_t)cols * 4, (size_t)Cc * 4, R, hipMemcpyDeviceToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemsetAsync(final_costs, 25, n, ctx->stream));
 
     clk.mark(5);
-    // the mesh lives across the iterations, as the reference's Fade_2D object does: the sparse matcher's points are
-    // triangulated at once, the resampling step's points are inserted into what is there
+    // By default the triangulation runs on the device, from the whole list each time (the mesh is a function of the point
+    // list alone, so this gives the triangles a growing mesh would hold).  With the option off the mesh lives on the host
+    // across the iterations, as the reference's Fade_2D object does: the sparse matcher's points are triangulated at once,
+    // the resampling step's points are inserted into what is there.
     struct MeshHolder {
         svx_mesh *m = nullptr;
         ~MeshHolder() { svx_mesh_destroy(m); }
     } mesh;
-    size_t in_mesh = 0;                      // support points (pairs) already handed to the mesh
-    // By default the triangulation runs on the device, from the whole list each time (the mesh is a function of the point
-    // list alone, so this gives the triangles the growing host mesh would hold); the host only appends the new points.
+    int in_mesh = 0;                         // support points already handed to the host mesh
     const bool mesh_on_device = svx_opt(ctx, SVX_OPT_MESH_ON_DEVICE) != 0 && R <= 8192 && Cc <= 8192;
     if (!mesh_on_device && prm->recordFullDisp && prm->nIters > 0 && svx_mesh_create(&mesh.m) != SVX_OK)
         return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: mesh");
+    if (prm->nIters > 1) {
+        fill_int_kernel<<<svx_cdiv((long)n, 256), 256, 0, ctx->stream>>>(owner, (long)n, 0x7fffffff);
+        SVX_LAUNCH_CHECK(ctx, "fill_int_kernel");
+    }
     for (int iter = 1; iter <= prm->nIters; ++iter) {                                                   // .cpp:451
         // plane table and interpolation of the prior over the whole frame (.cpp:454-466, :532-554)
         if (prm->recordFullDisp) {
             int n_tri = 0;
-            if (mesh_on_device) {
-                if (sup.size() > in_mesh) {
-                    void *pin;
-                    SVX_TRY(svx_pinned_reserve(ctx, (sup.size() - in_mesh) * sizeof(int32_t), &pin));
-                    memcpy(pin, sup.data() + in_mesh, (sup.size() - in_mesh) * sizeof(int32_t));
-                    SVX_HIP(ctx, hipMemcpyAsync(sup_dev + in_mesh, pin, (sup.size() - in_mesh) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-                    SVX_TRY(svx_pinned_mark_read(ctx));
-                    in_mesh = sup.size();
+            if (mesh_on_device) SVX_TRY(svx_mesh_plane_prior_device(ctx, sup_dev, n_sup, disparities, R, Cc, disparities, &n_tri));
+            else {
+                std::vector<int32_t> fresh(2 * (size_t)(n_sup - in_mesh) + 2);
+                if (n_sup > in_mesh) {
+                    SVX_HIP(ctx, hipMemcpyAsync(fresh.data(), sup_dev + 2 * (size_t)in_mesh, (size_t)(n_sup - in_mesh) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 }
-                SVX_TRY(svx_mesh_plane_prior_device(ctx, sup_dev, (int)(sup.size() / 2), disparities, R, Cc, disparities, &n_tri));
-            } else {
-                if (svx_mesh_insert(mesh.m, sup.data() + in_mesh, (int)((sup.size() - in_mesh) / 2)) != SVX_OK)
+                if (svx_mesh_insert(mesh.m, fresh.data(), n_sup - in_mesh) != SVX_OK)
                     return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "svx_high_perf_stereo: mesh insertion failed");
-                in_mesh = sup.size();
+                in_mesh = n_sup;
                 SVX_TRY(svx_mesh_prior(ctx, mesh.m, disparities, R, Cc, disparities, &n_tri));
             }
         }
@@ -252,39 +302,37 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         clk.mark(7);
         if (iter != prm->nIters) {                                                                      // .cpp:616-621
             const int gw = Cc / (int)occ + 1, gh = R / (int)occ + 1;
-            const size_t nc = (size_t)gw * gh;
+            const int n_slots = 2 * gw * gh;
             SVX_TRY(svx_support_resampling(ctx, cL, cR, R, Cc, 5, prm->costAggrWindowSize, gw, gh, conf_x, conf_y, conf_d, conf_c,
                                            inv_x, inv_y, inv_c, t_low, t_high, prm->maxDisp, disparities, rs_xy, rs_d, rs_valid));
-            std::vector<int32_t> hxy(4 * nc);
-            std::vector<uint8_t> hv(2 * nc);
-            SVX_HIP(ctx, hipMemcpyAsync(hxy.data(), rs_xy, hxy.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-            SVX_HIP(ctx, hipMemcpyAsync(hv.data(), rs_valid, hv.size(), hipMemcpyDeviceToHost, ctx->stream));
-            SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            for (size_t s = 0; s < 2 * nc; ++s)
-                if (hv[s]) insert_point(hxy[2 * s], hxy[2 * s + 1]);
+            // the accepted slots join the support list in slot order
+            resample_owner_kernel<<<svx_cdiv(n_slots, 256), 256, 0, ctx->stream>>>(rs_xy, rs_valid, n_slots, Cc, taken, owner);
+            SVX_LAUNCH_CHECK(ctx, "resample_owner_kernel");
+            resample_flags_kernel<<<svx_cdiv(n_slots, 256), 256, 0, ctx->stream>>>(rs_xy, rs_valid, n_slots, Cc, taken, owner, rank);
+            SVX_LAUNCH_CHECK(ctx, "resample_flags_kernel");
+            int added = 0;
+            SVX_TRY(read_total(n_slots, &added));
+            resample_emit_kernel<<<svx_cdiv(n_slots, 256), 256, 0, ctx->stream>>>(rs_xy, n_slots, Cc, rank, n_sup, sup_dev, taken, owner);
+            SVX_LAUNCH_CHECK(ctx, "resample_emit_kernel");
+            n_sup += added;
             occ = std::max(1u, occ / 2);
             clk.mark(8);
         }
     }
 
     // the support points themselves end up in the map, truncated to integers, and in the point list (.cpp:624-637)
-    const int n_sup = (int)(sup.size() / 2);
     if (n_sup) {
-        SVX_HIP(ctx, hipMemcpyAsync(stage_xy, sup.data(), (size_t)n_sup * 8, hipMemcpyHostToDevice, ctx->stream));
-        vertex_disparities_kernel<<<svx_cdiv(n_sup, 256), 256, 0, ctx->stream>>>(stage_xy, n_sup, Cc, disparities, final_disp);
+        vertex_disparities_kernel<<<svx_cdiv(n_sup, 256), 256, 0, ctx->stream>>>(sup_dev, n_sup, Cc, disparities, final_disp);
         SVX_LAUNCH_CHECK(ctx, "vertex_disparities_kernel");
     }
     SVX_HIP(ctx, hipMemcpy2DAsync(disparity_map, (size_t)cols * 4, final_disp, (size_t)Cc * 4, (size_t)Cc * 4, R, hipMemcpyDeviceToDevice, ctx->stream));
 
     // computed points: the high-gradient set in raster order, then the mesh vertices
     *n_points = n_hg + n_sup;
-    const int take_hg = std::min(n_hg, capacity);
+    const int take_hg = std::min(n_hg, capacity), take_sup = std::max(0, std::min(n_sup, capacity - n_hg));
     if (take_hg) SVX_HIP(ctx, hipMemcpyAsync(points_xy_host, pts, (size_t)take_hg * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (take_sup) SVX_HIP(ctx, hipMemcpyAsync(points_xy_host + 2 * (size_t)n_hg, sup_dev, (size_t)take_sup * 8, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < n_sup && n_hg + i < capacity; ++i) {
-        points_xy_host[2 * (size_t)(n_hg + i)] = sup[2 * i];
-        points_xy_host[2 * (size_t)(n_hg + i) + 1] = sup[2 * i + 1];
-    }
     clk.mark(9);
     return SVX_OK;
 }

@@ -131,6 +131,68 @@ __global__ __launch_bounds__(256) void sparse_consistency_kernel(const uint32_t 
     if (__any(reject) && lane == 0) m_first[l] = -1;
 }
 
+// The records of svx_sparse_match's host loop built on the device, for key points that are already there in raster
+// order (what svx_exfast_detect writes: sorted by (y, x), every position once; integer coordinates, so int(x + 0.5) = x).
+// Row offsets of the right list as sparsestereo-inl.h:145-169 fills them: offsets(j) = first right feature whose row is
+// >= j for j up to the last row below rows - 1 that holds a feature, and n_right beyond it.  The state rule (top rows
+// skipped, everything from the first feature in the bottom rows on invalidated) depends on the order only through the
+// row, because the list is sorted.
+__global__ void sparse_prepare_kernel(const int32_t *__restrict__ kl, int nl, const int32_t *__restrict__ kr, int nr, int rows, float y_tol,
+                                      SparseLeft *__restrict__ L, SparseRight *__restrict__ R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nr) {
+        SparseRight g;
+        g.xi = kr[2 * i]; g.yi = kr[2 * i + 1]; g.x = (float)g.xi; g.y = (float)g.yi;
+        R[i] = g;
+    }
+    if (i >= nl) return;
+    auto first_row_at_least = [&](int j) {            // lower bound over the right rows
+        int lo = 0, hi = nr;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (kr[2 * mid + 1] < j) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int lim = first_row_at_least(rows - 1);
+    const int last_row = lim > 0 ? kr[2 * (lim - 1) + 1] : -1;
+    auto offsets = [&](int j) { return j <= last_row ? first_row_at_least(j) : nr; };
+    SparseLeft f;
+    f.xi = kl[2 * i]; f.yi = kl[2 * i + 1]; f.x = (float)f.xi; f.y = (float)f.yi;
+    const int ly = f.yi;
+    auto clampi = [rows](int v) { return min(rows - 1, max(0, v)); };
+    f.r_start = offsets(clampi((int)((float)ly - y_tol)));
+    f.r_end = offsets(clampi((int)((float)ly + y_tol) + 2));
+    f.state = ly >= max(2, rows - 3) ? 2 : (ly < 2 ? 1 : 0);
+    L[i] = f;
+}
+
+// svx_sparse_match for device-resident key-point lists in raster order: first_dev[i] = index of left feature i's match
+// in the right list or -1, cost_dev[i] its cost (as svx_sparse_match's records, in the order of the left list).
+int svx_sparse_match_lists(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, const int32_t *left_xy,
+                           int n_left, const int32_t *right_xy, int n_right, int max_disparity, float y_tolerance, float uniqueness,
+                           int left_right_step, int *first_dev, int *cost_dev) {
+    SVX_REQUIRE(ctx, cols <= 32767, SVX_ERR_UNSUPPORTED, "svx_sparse_match: cols above 32767 (epiline table is 16-bit)");
+    SVX_REQUIRE(ctx, left_right_step >= 1 && uniqueness > 0.0f, SVX_ERR_INVALID_ARG, "svx_sparse_match: bad step or uniqueness");
+    if (n_left == 0 || n_right == 0) return SVX_OK;
+    const size_t lbytes = sizeof(SparseLeft) * (size_t)n_left, rbytes = sizeof(SparseRight) * (size_t)n_right;
+    const size_t ro_off = (lbytes + 255) & ~(size_t)255, total = ro_off + rbytes;
+    void *ws;
+    int rc = svx_ws_reserve(ctx, total, &ws);
+    if (rc) return rc;
+    SparseLeft *dl = (SparseLeft *)ws;
+    SparseRight *dr = (SparseRight *)((char *)ws + ro_off);
+    sparse_prepare_kernel<<<svx_cdiv(std::max(n_left, n_right), 256), 256, 0, ctx->stream>>>(left_xy, n_left, right_xy, n_right, rows, y_tolerance, dl, dr);
+    SVX_LAUNCH_CHECK(ctx, "sparse_prepare_kernel");
+    const unsigned grid = svx_cdiv(n_left, 4);
+    sparse_calc_costs_kernel<<<grid, 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, dl, n_left, dr, max_disparity, y_tolerance, first_dev, cost_dev);
+    SVX_LAUNCH_CHECK(ctx, "sparse_calc_costs_kernel");
+    sparse_consistency_kernel<<<grid, 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, dl, n_left, dr, max_disparity, uniqueness,
+                                                            left_right_step, first_dev, cost_dev);
+    SVX_LAUNCH_CHECK(ctx, "sparse_consistency_kernel");
+    return SVX_OK;
+}
+
 SVX_API int svx_sparse_match(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols,
                              const float *left_xy_host, int n_left, const float *right_xy_host, int n_right,
                              int max_disparity, float y_tolerance, float uniqueness, int left_right_step,
