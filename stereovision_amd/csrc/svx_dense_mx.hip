@@ -255,7 +255,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
         if constexpr (WORDS == 2 || STEADY || j <= 2) {
             const mx_v8i b = mx_frag(fb[s % P]);
             const mx_v8i a = WORDS == 2 ? (j >= 5 ? ao[k] : an[k]) : (!STEADY && j == 2 ? ao[2] : an[j]);
-            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[t], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[t], 4, 4, 0, 0, 0, 0);   // zero scale arguments select v_mfma_f32_32x32x64_f8f6f4, the form without scale operands (same products, shorter encoding, issues faster)
         }
         asm volatile("" : "+v"(acc[t]));      // keeps the instruction at this place among the ordered statements around it
         if constexpr (s == MEET) mx_meet();
