@@ -152,7 +152,8 @@ __device__ __forceinline__ void mx_meet() {
 template <int T, bool EDGE>
 __device__ __forceinline__ float mx_elem_l(const mx_v16f (&acc)[T], const MxState<T> &st, int u, int i) { return EDGE ? acc[u][i] + st.pen_l[u] : acc[u][i]; }
 template <int T, bool EDGE>
-__device__ __forceinline__ float mx_elem_r(const mx_v16f (&acc)[T], const MxState<T> &st, int u, int i) { return EDGE ? acc[u][i] + st.pen_r[i] : acc[u][i]; }
+// (only the last three left columns of an x-block can lie beyond cols - 6: registers 13..15 of the upper lane half)
+__device__ __forceinline__ float mx_elem_r(const mx_v16f (&acc)[T], const MxState<T> &st, int u, int i) { return EDGE && i >= 13 ? acc[u][i] + st.pen_r[i] : acc[u][i]; }
 
 // Right view, tile u: the best key of each right column over the tile's 32 left columns, in three pieces.
 template <int T, bool EDGE, int U>
