@@ -343,7 +343,7 @@ int svx_delaunay(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, int32_t *t
 /* The same triangulation computed on the device (device points in, device index triples out, in svx_delaunay's
  * order; *n_tri_host on the host, the call synchronises): every point finds the triangles around it from the points
  * near it, and the points that cannot be sure (next to large empty areas, on the hull) from all points.  Points
- * must lie inside a rows x cols frame of at most 8192 x 8192.  SVX_ERR_UNSUPPORTED for a point set with more than 64
+ * must lie inside a rows x cols frame of at most 8192 x 8192.  SVX_ERR_UNSUPPORTED for a point set with more than 256
  * triangles around one point (or 32 led by one point): svx_delaunay takes those.
  * svx_mesh_plane_prior_device is svx_mesh_plane_prior with the points on the device and the triangulation done there
  * (it falls back to the host triangulation by itself where svx_delaunay_device would refuse).

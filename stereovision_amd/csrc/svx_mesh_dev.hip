@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int MAX_RING = 64;              // triangles around one point; a longer ring sends the call back to the host triangulation
+constexpr int MAX_RING = 256;             // triangles around one point (a loop bound; fans along the frame's border lines reach dozens); a longer ring sends the call back to the host triangulation
 constexpr int MAX_LEAD = 32;              // triangles one point leads (it has the smallest index of the three)
 
 struct DPt { int x, y, id; };
@@ -47,17 +47,6 @@ __device__ __forceinline__ int d_in_circle(const DPt &a, const DPt &b, const DPt
     else if (m == c.id) o = d_orient(a, b, d);
     else o = -d_orient(a, b, c);
     return o > 0 ? 1 : (o < 0 ? -1 : 0);
-}
-
-// Does the circle through p, a, b stay within distance `reach` of p?  It does when its diameter is at most `reach`:
-// 4 r^2 = |pa|^2 |pb|^2 |ab|^2 / cross^2 <= reach^2, evaluated in double with a margin on the safe side.
-__device__ __forceinline__ bool circle_within(const DPt &p, const DPt &a, const DPt &b, int reach) {
-    if (reach < 0) return true;                                  // nothing lies outside the staged region
-    const double la = (double)((a.x - p.x) * (a.x - p.x) + (a.y - p.y) * (a.y - p.y));
-    const double lb = (double)((b.x - p.x) * (b.x - p.x) + (b.y - p.y) * (b.y - p.y));
-    const double lc = (double)((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y));
-    const double cr = (double)d_orient(p, a, b);
-    return la * lb * lc <= (double)reach * (double)reach * cr * cr * 0.999999;
 }
 
 // The circle through p, a, b as centre (relative to p) and squared radius in double, a little enlarged: a candidate
@@ -164,6 +153,24 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
         if (cy - W > 0) reach = min(reach, p.y - ((cy - W) << shift));
         if (cy + W + 1 < gh) reach = min(reach, ((cy + W + 1) << shift) - 1 - p.y);
         if (reach == 0x7fffffff) reach = -1;
+        // The held window as a pixel box, and the frame around it.  A circle (or half-plane) that meets no part of the frame
+        // outside the box can hold no point that is not among the held candidates: the four rectangles of the frame outside
+        // the box are tested one by one (this also passes the large circles of the flat triangles along the hull, most of
+        // which lie outside the frame).
+        const int bx0 = max(cx - W, 0) << shift, bx1 = (min(cx + W + 1, gw) << shift) - 1;
+        const int by0 = max(cy - W, 0) << shift, by1 = (min(cy + W + 1, gh) << shift) - 1;
+        const int X1 = (gw << shift) - 1, Y1 = (gh << shift) - 1;
+        auto circle_in_box = [&](const Circle &c) -> bool {
+            if (reach < 0) return true;
+            if (reach == 0) return false;                     // (mode 1 with nothing held)
+            const double mx = (double)p.x + c.ox, my = (double)p.y + c.oy;
+            auto clear = [&](int x0, int y0, int x1, int y1) {
+                if (x0 > x1 || y0 > y1) return true;
+                const double dx = fmax(fmax((double)x0 - mx, mx - (double)x1), 0.0), dy = fmax(fmax((double)y0 - my, my - (double)y1), 0.0);
+                return dx * dx + dy * dy > c.r2 + 1e-6;
+            };
+            return clear(0, 0, bx0 - 1, Y1) && clear(bx1 + 1, 0, X1, Y1) && clear(bx0, 0, bx1, by0 - 1) && clear(bx0, by1 + 1, bx1, Y1);
+        };
         // the 7 x 7 cells around the point into registers (mode 0): the row bounds are read by independent loads
         int2 c0 = none, c1 = none;
         int n_near = 0;
@@ -304,10 +311,7 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
             const int2 a0c = bc;
             bool open = false;
             for (int dir = 0; dir < 2 && verdict == 0; ++dir) {          // 0: counter-clockwise from a0; 1: clockwise, for an open ring
-                if (dir == 1) {
-                    if (!open) break;
-                    if (MODE == 0 && reach >= 0) { verdict = -1; break; }  // a hull point: only the whole point set can tell
-                }
+                if (dir == 1 && !open) break;
                 DPt a = unpack(a0c);
                 int axy = a0c.x;
                 for (int step = 0;; ++step) {
@@ -341,7 +345,18 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                     };
                     near(rank);
                     rank_meet();
-                    if (MODE == 1 && bkc.y < 0) {
+                    // No held candidate on the searched side: p -> a is a hull edge if no point outside the held window lies there
+                    // either, which is certain when the part of the frame outside the window's box (up to four rectangles) lies
+                    // wholly on the other side of the line: a rectangle does when its four corners do.
+                    bool side_empty = false;
+                    if (bkc.y < 0 && !(MODE == 1 && n_wide == 0)) {
+                        auto away = [&](int x, int y) { const int o = ax * (y - p.y) - ay * (x - p.x); return dir == 0 ? o <= 0 : o >= 0; };
+                        auto clear = [&](int x0, int y0, int x1, int y1) {
+                            return x0 > x1 || y0 > y1 || (away(x0, y0) && away(x1, y0) && away(x0, y1) && away(x1, y1));
+                        };
+                        side_empty = clear(0, 0, bx0 - 1, Y1) && clear(bx1 + 1, 0, X1, Y1) && clear(bx0, 0, bx1, by0 - 1) && clear(bx0, by1 + 1, bx1, Y1);
+                    }
+                    if (MODE == 1 && bkc.y < 0 && !side_empty) {
                         far(rank, side_cols);
                         rank_meet();
                         if (NW > 1) {
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                         }
                     };
                     near(hands);
-                    if (MODE == 1 && !(bcc.y >= 0 && circle_within(p, a, b, reach))) {
+                    if (MODE == 1 && !side_empty && !(bcc.y >= 0 && circle_in_box(circ))) {
                         // the searched side of the line p -> a and, if there is a winner, its circle
                         const bool has = bcc.y >= 0;
                         const double mx = (double)p.x + circ.ox, my = (double)p.y + circ.oy, mr = has ? sqrt(circ.r2) : 0.0;
@@ -390,8 +405,12 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                                 if (beats(win[v])) { bcc = win[v]; b = unpack(bcc); circ.set(p, a, b); }
                         }
                     }
-                    if (bcc.y < 0) { if (dir == 0) open = true; break; }
-                    if (MODE == 0 && !circle_within(p, a, b, reach)) { verdict = -1; break; }
+                    if (bcc.y < 0) {
+                        if (MODE == 0 && reach >= 0 && !side_empty) verdict = -1;      // only more points can tell whether this is a hull edge
+                        if (dir == 0) open = true;
+                        break;
+                    }
+                    if (MODE == 0 && !circle_in_box(circ)) { verdict = -1; break; }
                     const DPt u = dir == 0 ? a : b, v2 = dir == 0 ? b : a;     // triangle (p, u, v2), counter-clockwise
                     if (p.id < u.id && p.id < v2.id) {
                         if (n_lead >= MAX_LEAD) { verdict = -2; break; }

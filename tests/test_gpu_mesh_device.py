@@ -108,6 +108,25 @@ def test_collinear_tiny_and_repeated(ctx):
     assert np.array_equal(got, want)
 
 
+def test_fans(ctx):
+    """A point next to a long line of collinear points is joined to every one of them: a ring of a hundred triangles on the
+    device (the detector's border margin produces such lines along the frame), and a point that leads more triangles than
+    the device form holds (the apex comes first in the list) is handed to the host triangulation by the prior entry point."""
+    import stereovision_amd as S
+    rows, cols = 300, 40
+    line = np.stack([np.full(100, 20), np.arange(10, 210, 2)], 1)
+    apex_last = np.concatenate([line, [[19, 111]]])
+    got, want = both(ctx, apex_last, rows, cols)
+    assert np.array_equal(got, want) and len(want) == 99
+    apex_first = np.concatenate([[[19, 111]], line])
+    with pytest.raises(S.SvxError):
+        ctx.delaunay_device(dev(apex_first.astype(np.int32)), rows, cols)
+    disp = np.random.default_rng(0).random((rows, cols)).astype(np.float32) * 9
+    want_p, nt_h = ctx.mesh_plane_prior(apex_first, dev(disp), dev(np.zeros((rows, cols), np.float32)))
+    got_p, nt_d = ctx.mesh_plane_prior_device(dev(apex_first.astype(np.int32)), dev(disp), dev(np.zeros((rows, cols), np.float32)))
+    assert nt_h == nt_d == 99 and np.array_equal(got_p.cpu().numpy(), want_p.cpu().numpy())
+
+
 def test_points_on_the_frame(ctx):
     rows, cols = 48, 80
     edge = [[x, 0] for x in range(0, cols, 3)] + [[x, rows - 1] for x in range(0, cols, 5)] + [[0, y] for y in range(1, rows - 1, 4)] + \
