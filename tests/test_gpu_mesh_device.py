@@ -108,6 +108,35 @@ def test_collinear_tiny_and_repeated(ctx):
     assert np.array_equal(got, want)
 
 
+def test_many_small_configurations(ctx):
+    """Sixty seeded point sets of random size, frame and shape (uniform, clustered, on a coarse lattice, with repeats)."""
+    for seed in range(60):
+        rng = np.random.default_rng(1000 + seed)
+        rows, cols = int(rng.integers(8, 400)), int(rng.integers(8, 400))
+        n = int(rng.integers(3, 4000))
+        kind = seed % 4
+        if kind == 0:
+            pts = unique_random(rng, rows, cols, n)
+        elif kind == 1:                                        # a few blobs
+            c = rng.integers(0, [cols, rows], size=(4, 2))
+            pts = c[rng.integers(0, 4, n)] + rng.normal(0, 6, size=(n, 2)).astype(np.int64)
+            pts = pts[(pts[:, 0] >= 0) & (pts[:, 0] < cols) & (pts[:, 1] >= 0) & (pts[:, 1] < rows)]
+        elif kind == 2:                                        # lattice of step 2..5 with holes
+            step = int(rng.integers(2, 6))
+            ys, xs = np.mgrid[0:rows:step, 0:cols:step]
+            pts = np.stack([xs.ravel(), ys.ravel()], 1)
+            pts = pts[rng.random(len(pts)) < 0.7]
+        else:                                                  # repeats
+            base = unique_random(rng, rows, cols, max(3, n // 3))
+            pts = base[rng.integers(0, len(base), n)]
+        pts = np.ascontiguousarray(pts, np.int32)
+        rng.shuffle(pts)
+        if len(pts) == 0:
+            continue
+        got, want = both(ctx, pts, rows, cols)
+        assert np.array_equal(got, want), (seed, rows, cols, len(pts))
+
+
 def test_fans(ctx):
     """A point next to a long line of collinear points is joined to every one of them: a ring of a hundred triangles on the
     device (the detector's border margin produces such lines along the frame), and a point that leads more triangles than
