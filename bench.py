@@ -339,8 +339,8 @@ def main():
         }
         if on_matrix_cores:
             # The kernel forms the cost values as fp4 dot products, so it is priced against the dense fp4 matrix peak:
-            # algorithmic work = per pix*disp one 5-column x 64-bit dot product for the census row that enters the 5-row
-            # window and one for the row that leaves it = 2 * 5 * 64 multiply-adds = 1280 flop.  The vector-popcount
+            # algorithmic work = per pix*disp one 5-column dot product over the descriptor bits for the census row that enters the
+            # 5-row window and one for the row that leaves it = 2 * 5 * 64 multiply-adds = 1280 flop with 64-bit descriptors.  The vector-popcount
             # pricing used for the sweep kernel (2 lane-instructions per descriptor word and pix*disp) stays beside it.
             tiles, passes = (3 if D <= 64 else 5), max(1, -(-D // 128))       # more than 128 disparities: passes of 128 (five tiles each)
             # strips as svx_launch_mx_sweep chooses them (a strip's first five rows have nothing leaving the window yet)
@@ -350,9 +350,12 @@ def main():
             k_best = min(range(1, min(16, rows - 4) + 1), key=lambda k: (cost(k), k))
             strip_rows = -(-(rows - 4) // k_best)
             strips = -(-(rows - 4) // strip_rows)
-            mfma_count = passes * tiles * (10 * (rows - 4 + 4 * strips) - 25 * strips) * ((cols - 4 + 31) // 32) * F
+            # two-word descriptors: ten products per tile and row (five while a strip's first five rows fill the window); one-word
+            # descriptors put two window pixels in one product: five per tile and row (three while the window fills)
+            per_tile = (10 * (rows - 4 + 4 * strips) - 25 * strips) if words == 2 else (5 * (rows - 4 + 4 * strips) - 10 * strips)
+            mfma_count = passes * tiles * per_tile * ((cols - 4 + 31) // 32) * F
             issued_flops = 2.0 * 32 * 32 * 64 * mfma_count
-            alg_flops = 1280.0 * pixdisp_per_frame * F
+            alg_flops = 2.0 * 2 * 5 * 32 * words * pixdisp_per_frame * F
             # The headline stays the vector-popcount floor (one xor + one popcount per descriptor word and pix*disp), the
             # pricing every kernel choice shares; the matrix work this kernel really issues is reported beside it.
             roofline["mfma"] = {
@@ -362,7 +365,7 @@ def main():
                 "issued_frac": round(issued_flops / (k_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4),
                 "window_flops_per_launch": alg_flops, "window_frac": round(alg_flops / (k_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4),
                 "note": "cost values as fp4 dot products on the matrix cores: issued = every matrix instruction of the launch (tiles are "
-                        "32 disparities wider than the search, strips carry 4 halo rows); window = 2 x 5 x 64 multiply-adds per pix*disp "
+                        "32 disparities wider than the search, strips carry 4 halo rows); window = 2 x 5 x (32 per descriptor word) multiply-adds per pix*disp "
                         "(the census row entering and the one leaving the 5-row window), this kernel's own formulation, not the contract's unit",
             }
         if both_views:
