@@ -40,6 +40,8 @@ constexpr int MX_M = 32;                 // left columns per wavefront
 #define MX_W 4                           // wavefronts (x-blocks of 32 left columns) per workgroup: they share one staged image of the census rows
 #endif
 constexpr int MX_NBUF = 3;               // staged rows in flight: the one being read, the one being written, and one in between (see mx_strip)
+constexpr int MX_KROWS = 3;              // right view: key rows in LDS (the one being written out, the one being filled, and the next one the wavefronts ahead fill)
+constexpr float MX_NO_KEY = -4194304.0f; // below every key, admissible or not
 
 template <int T, int WORDS = 2>
 struct MxGeom {
@@ -58,6 +60,11 @@ struct MxGeom {
     // One-word descriptors: a single plane (the two k-halves of an instruction are two different pixels, see mx_row).
     static constexpr int PLANE = WORDS == 2 ? PX + (12 - PX % 8) % 8 + MX_PLANE_PAD : PX;
     static constexpr int SLOTS = WORDS * PLANE;
+    // Right view: the workgroup's x-blocks merge their best keys per right column in LDS before they leave for memory.  A key
+    // row holds the 32 (MX_W + T - 1) right columns the workgroup's tiles cover (column xl0_wg - 32 (T - 1) - d_base first);
+    // MX_KROWS rows are in use at a time (see mx_keys_flush).
+    static constexpr int NKEYS = 32 * (MX_W + T - 1);
+    static constexpr int KEY_ROUNDS = (NKEYS + 64 * MX_W - 1) / (64 * MX_W);   // keys per thread when a row is written out
     static_assert(WORDS == 1 || MX_PLANE_PAD != 0 || PLANE % 8 == 4, "plane offset must alternate the bank halves of a store");
 };
 
@@ -138,8 +145,15 @@ struct MxState {
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
     float pen_l[T], pen_r[16];                               // border blocks: what each view must not use (0 or -2^21)
     float *out;                                              // left map: this lane's pixel of the row being written
-    float *part;                                             // right view: this lane's slot of the row being written
-    long part_stride, out_stride;
+    long out_stride;
+    // right view (see mx_keys_flush)
+    float *key0;                                             // this lane's slot for tile 0 in key row 0 (LDS)
+    float *kcur;                                             // the same in the key row being filled
+    float *kflush0;                                          // this thread's first key of key row 0
+    int krow;                                                // key row being filled
+    float kv[G::KEY_ROUNDS];                                 // keys on their way out
+    float *part;                                             // where this thread's first key of the next finished row goes
+    long part_stride;
 };
 
 // The workgroup's meeting point.  No wait is attached: what a wavefront must have finished (its staging writes) is
@@ -170,11 +184,40 @@ __device__ __forceinline__ void mx_right_b(const mx_v16f (&acc)[T], const MxStat
     x[0] = mx_max3(x[0], x[3], x[4]);
     x[0] = mx_max(x[0], mx_elem_r<T, EDGE>(acc, st, U, 15));
 }
-template <int U>
-__device__ __forceinline__ void mx_right_c(float *__restrict__ part, const float (&x)[5], int swap32) {
-    // the other half of the wavefront holds the other 16 left columns of the same right column
-    const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(swap32, __builtin_bit_cast(int, x[0])));
-    part[U * 32] = mx_max(x[0], o);                          // lanes l and l ^ 32 write the same value to the same place
+// Both lane halves hold left columns of the same right column; the workgroup's other x-blocks cover it as well: all of
+// them meet in the key row (a 4-byte LDS operation serves the two halves in different cycles, so equal addresses do not collide).
+template <int T, int U>
+__device__ __forceinline__ void mx_right_c(MxState<T> &st, const float (&x)[5]) {
+    __hip_atomic_fetch_max(st.kcur + U * 32, x[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The next output row's keys go to the next key row.
+template <int T>
+__device__ __forceinline__ void mx_keys_next_row(MxState<T> &st) {
+    st.krow = st.krow == MX_KROWS - 1 ? 0 : st.krow + 1;
+    st.kcur = st.key0 + st.krow * MxState<T>::G::NKEYS;
+}
+// Writing out a finished key row, in two pieces (LDS read; store and reset).  The keys of output row r are complete when
+// every wavefront has passed the meeting point of the census row after it (its last tile is read during that row's first
+// products): the row is written out behind that point, while the wavefronts fill the row after it and, those that are ahead,
+// the one after that, which is why three key rows are in use.  Key row `which` (0: the one being filled, MX_KROWS - 1: the one before it).
+template <int T>
+__device__ __forceinline__ void mx_keys_flush_read(MxState<T> &st, int which) {
+    using G = typename MxState<T>::G;
+    const int kr = st.krow + which >= MX_KROWS ? st.krow + which - MX_KROWS : st.krow + which;
+#pragma unroll
+    for (int i = 0; i < G::KEY_ROUNDS; ++i) st.kv[i] = st.kflush0[kr * G::NKEYS + i * 64 * MX_W];   // (a thread without a key in the last round reads inside the LDS block)
+}
+template <int T>
+__device__ __forceinline__ void mx_keys_flush_write(MxState<T> &st, int which, int tid) {
+    using G = typename MxState<T>::G;
+    const int kr = st.krow + which >= MX_KROWS ? st.krow + which - MX_KROWS : st.krow + which;
+#pragma unroll
+    for (int i = 0; i < G::KEY_ROUNDS; ++i)
+        if ((i + 1) * 64 * MX_W <= G::NKEYS || tid + i * 64 * MX_W < G::NKEYS) {
+            st.part[i * 64 * MX_W] = st.kv[i];
+            st.kflush0[kr * G::NKEYS + i * 64 * MX_W] = MX_NO_KEY;
+        }
+    st.part += st.part_stride;
 }
 
 // Decodes the winner of a left pixel: key = window score + (1023 - d) / 1024; an inadmissible pair sits near -2^20.
@@ -223,7 +266,7 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane, int pas
 // and fifth instruction are skipped and the third multiplies its second half by zero.
 template <int T, int WORDS, bool STEADY, bool BOTH, bool EDGE>
 __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &ptr, uint4 *stage_e, uint4 *stage_l, MxState<T> &st,
-                                       mx_v8i (&an)[5], uint4 (&fb)[MX_P], long off_new, long off_old, int lane, int swap32, int pass_flags) {
+                                       mx_v8i (&an)[5], uint4 (&fb)[MX_P], long off_new, long off_old, int lane, int tid, int pass_flags) {
     using G = MxGeom<T, WORDS>;
     constexpr int PER = WORDS == 2 && STEADY ? 10 : 5, S = T * PER, P = MX_P;
     constexpr int MEET = mx_meet_step<T, PER>();
@@ -328,14 +371,18 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
                 if constexpr (j == 4) mx_right_a<T, EDGE, u>(acc, st, rx);
                 if constexpr (j == 8) mx_right_b<T, EDGE, u>(acc, st, rx);
                 if constexpr (j == 9) {
-                    mx_right_c<u>(st.part, rx, swap32);
-                    if constexpr (t == 0) st.part += st.part_stride;  // the following tiles belong to this row
+                    mx_right_c<T, u>(st, rx);
+                    if constexpr (t == 0) mx_keys_next_row<T>(st);    // the following tiles belong to this row
                 }
             }
         };
         if constexpr (STEADY && !(MX_X & 2)) {
             if constexpr (PER == 10) select(std::integral_constant<int, j>{});
             else { select(std::integral_constant<int, 2 * j>{}); select(std::integral_constant<int, 2 * j + 1>{}); }
+            if constexpr (BOTH) {                            // every wavefront has passed the meeting point: the previous output row's keys are complete
+                if constexpr (s == MEET + 1) mx_keys_flush_read<T>(st, MX_KROWS - 1);
+                if constexpr (s == MEET + 3) mx_keys_flush_write<T>(st, MX_KROWS - 1, tid);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -343,7 +390,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
 
 // Between the first five rows and the steady state: the first output row's tiles 0 .. T-2.
 template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState<T> &st, int swap32) {
+__device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState<T> &st) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         float b = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
@@ -357,14 +404,14 @@ __device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState
             float rx[5];
             mx_right_a<T, EDGE, u>(acc, st, rx);
             mx_right_b<T, EDGE, u>(acc, st, rx);
-            mx_right_c<u>(st.part, rx, swap32);
+            mx_right_c<T, u>(st, rx);
         });
     }
 }
 
 // After the last row of a strip: its last tile, the lane reduction and the stores (nothing follows to hide them behind).
 template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<T> &st, int lane, int swap32, int pass_flags) {
+__device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<T> &st, int lane, int tid, int pass_flags) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (T == 5) st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, 3, i));
@@ -381,7 +428,10 @@ __device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<
         float rx[5];
         mx_right_a<T, EDGE, T - 1>(acc, st, rx);
         mx_right_b<T, EDGE, T - 1>(acc, st, rx);
-        mx_right_c<T - 1>(st.part, rx, swap32);
+        mx_right_c<T, T - 1>(st, rx);
+        __syncthreads();                                     // the last output row's keys are complete
+        mx_keys_flush_read<T>(st, 0);
+        mx_keys_flush_write<T>(st, 0, tid);
     }
 }
 
@@ -400,7 +450,6 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
     const int r0 = xl0 - 32 * (T - 1) - d_base;      // right column of tile 0, lane 0 (this pass searches disparities d_base .. d_base + 32 (T - 1) - 1)
-    const int swap32 = (lane ^ 32) * 4;
 
     // Accumulator element i of tile t is (left column xl0 + m, right column r0 + 32 t + n).  It starts at
     // (1023 - d) / 1024, so that the running window score carries its disparity tag below the integer part
@@ -448,8 +497,17 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     st.out = disp + (long)y_lo * cols + xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h;
     st.own = xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h >= own_from;
     st.out_stride = cols;
-    st.part = part_row0 + n;
-    st.part_stride = part_stride;
+    if (BOTH) {
+        // key rows behind the staged images; tile u of this wavefront covers right columns xl0 - 32 (T - 1) - d_base + 32 u + n
+        float *const keys = reinterpret_cast<float *>(lds + MX_NBUF * 2 * G::SLOTS);
+        for (int i = tid; i < MX_KROWS * G::NKEYS; i += 64 * MX_W) keys[i] = MX_NO_KEY;   // (the meeting behind the first staged row covers this)
+        st.key0 = keys + (xl0 - xl0_wg) + n;
+        st.kcur = st.key0;
+        st.krow = 0;
+        st.kflush0 = keys + tid;
+        st.part = part_row0 + tid;
+        st.part_stride = part_stride;
+    }
 
     // image b: entering row at lds + 2 b SLOTS, leaving row behind it
     auto img_e = [&](int b) -> uint4 * { return lds + (2 * b) * G::SLOTS; };
@@ -499,21 +557,21 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
 #pragma unroll 1
     for (int r = 0; r < 5; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)max(r - 3, 0) * row_words;
-        mx_row<T, WORDS, false, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32, pass_flags);
+        mx_row<T, WORDS, false, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, tid, pass_flags);
         b_cur = b_nxt;
         b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
         point(b_cur, b_nxt);
     }
-    mx_first_output<T, BOTH, EDGE>(acc, st, swap32);
+    mx_first_output<T, BOTH, EDGE>(acc, st);
 #pragma unroll 1
     for (int r = 5; r < n_rows; ++r) {
         const long on = (long)min(r + 2, last) * row_words, oo = (long)(r - 3) * row_words;
-        mx_row<T, WORDS, true, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, swap32, pass_flags);
+        mx_row<T, WORDS, true, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, tid, pass_flags);
         b_cur = b_nxt;
         b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
         point(b_cur, b_nxt);
     }
-    mx_last_output<T, BOTH, EDGE>(acc, st, lane, swap32, pass_flags);
+    mx_last_output<T, BOTH, EDGE>(acc, st, lane, tid, pass_flags);
 }
 
 // grid: (groups of MX_W x-blocks, strips, frames), MX_W wavefronts per block, one per x-block.  x-block b owns output
@@ -521,14 +579,15 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
 // a wavefront behind the last x-block repeats it (same results to the same places).
 // Searches disparities d_base .. min(max_disp, d_base + 32 (T - 1)) - 1; a wider range takes several launches (pass_flags:
 // mx_reduce_tail).  Requires cols >= 36, rows >= 5.
-// BOTH: also stores, for every output row and x-block, the right view's best key of each of the block's 32 T right
-// columns over the block's left columns: partial[frame][row][x-block][32 T] (svx_mx_right_disparity merges them).
+// BOTH: also stores, for every output row and workgroup, the right view's best key of each of the 32 (MX_W + T - 1) right
+// columns the workgroup's tiles cover, over the workgroup's left columns: partial[frame][row][workgroup][NKEYS]
+// (svx_mx_right_disparity merges the workgroups that reach a right pixel).
 template <int T, int WORDS, bool BOTH>
 __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                           int rows, int cols, int max_disp, int d_base, int pass_flags, int strip_rows, int n_xblocks,
                                                           float *__restrict__ disp_all, int write_border, float *__restrict__ partial) {
     using G = MxGeom<T, WORDS>;
-    __shared__ uint4 lds[MX_NBUF * 2 * G::SLOTS];    // [image][entering row, leaving row][see MxGeom]
+    __shared__ uint4 lds[MX_NBUF * 2 * G::SLOTS + (BOTH ? MX_KROWS * G::NKEYS / 4 : 0)];    // [image][entering row, leaving row][see MxGeom], then the right view's key rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int n = lane & 31, h = lane >> 5;
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
@@ -546,8 +605,8 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     const int xl0 = min(2 + bx * MX_M, cols - 2 - MX_M), xl0_wg = min(2 + (int)gx * MX_W * MX_M, cols - 2 - MX_M);
     const int y_lo = 2 + (int)by * strip_rows, y_hi = min(y_lo + strip_rows, rows - 2);
     const int n_rows = y_hi - y_lo + 4;              // census rows y_lo-2 .. y_hi+1
-    const long part_stride = (long)n_xblocks * (32 * T);
-    float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)bx * (32 * T) : nullptr;
+    const long part_stride = (long)gridDim.x * G::NKEYS;
+    float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)gx * G::NKEYS : nullptr;
     // blocks in which the two views admit different pairs
     const bool edge = BOTH && (xl0 - 32 * (T - 1) - d_base < 5 || xl0 + MX_M - 1 > cols - 6);
     if (edge) mx_strip<T, WORDS, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
@@ -566,55 +625,58 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
 }
 
 // Right view from the partial keys: right pixel xr can match left columns xr .. xr + max_disp - 1.  Within one pass
-// (disparities d_base .. d_base + 32 (T - 1) - 1) they lie in the x-blocks whose first left column xl0 satisfies
-// xs - 31 <= xl0 <= xs + 32 (T - 1) with xs = xr + d_base; block b keeps xr in slot xs - (xl0 - 32 (T - 1)).
-// Returns the best key of that pass.
+// (disparities d_base .. d_base + 32 (T - 1) - 1) they lie in the workgroups (groups of MX_W x-blocks) whose first left
+// column X satisfies xs - 32 MX_W < X <= xs + 32 (T - 1) with xs = xr + d_base; group g keeps xr in slot xs - (X - 32 (T - 1))
+// of its key row.  Returns the best key of that pass.
 template <int T>
-__device__ __forceinline__ float svx_mx_right_key(const float *__restrict__ prow, int xs, int cols, int n_xblocks) {
-    float best = -1048576.0f;
-    const int b_first = max((xs - 31 - 2 + MX_M - 1) / MX_M, 0);       // smallest b with 2 + 32 b >= xs - 31
-    if (xs >= 2 && b_first + T - 1 < n_xblocks - 1) {
-        // all regular blocks (xl0 = 2 + 32 b): exactly T of them reach xs, block b_first + k in slot ((xs - 2) & 31) + 32 (T - 1 - k)
-        const float *p = prow + (long)b_first * (32 * T) + ((xs - 2) & 31) + 32 * (T - 1);
+__device__ __forceinline__ float svx_mx_right_key(const float *__restrict__ prow, int xs, int cols, int n_groups) {
+    constexpr int GW = 32 * MX_W, NK = MxGeom<T>::NKEYS, K = (NK + GW - 1) / GW;
+    float best = MX_NO_KEY;
+    const int a = xs >= 2 ? (xs - 2) / GW : -1;
+    if (a >= 0 && a + K - 1 < n_groups - 1) {
+        // all regular groups (X = 2 + GW g): group a + k holds xs in slot (xs - 2) % GW + 32 (T - 1) - GW k while that is not negative
+        const int slot = (xs - 2) - a * GW + 32 * (T - 1);
+        const float *p = prow + (long)a * NK + slot;
 #pragma unroll
-        for (int k = 0; k < T; ++k) best = fmaxf(best, p[k * (32 * T - 32)]);
+        for (int k = 0; k < K; ++k)
+            if (slot - GW * k >= 0) best = fmaxf(best, p[k * (NK - GW)]);
         return best;
     }
 #pragma unroll
-    for (int k = 0; k < T + 1; ++k) {
-        const int b = min(b_first + k, n_xblocks - 1);
-        const int xl0 = min(2 + b * MX_M, cols - 2 - MX_M);
-        const int slot = xs - (xl0 - 32 * (T - 1));
-        const bool ok = slot >= 0 && slot < 32 * T;
-        const float v = prow[(long)b * (32 * T) + min(max(slot, 0), 32 * T - 1)];
-        best = fmaxf(best, ok ? v : -1048576.0f);
+    for (int k = 0; k < K + 1; ++k) {
+        const int g = min(max(a, 0) + k, n_groups - 1);
+        const int X = min(2 + g * GW, cols - 2 - MX_M);
+        const int slot = xs - (X - 32 * (T - 1));
+        const bool ok = slot >= 0 && slot < NK;
+        const float v = prow[(long)g * NK + min(max(slot, 0), NK - 1)];
+        best = fmaxf(best, ok ? v : MX_NO_KEY);
     }
     return best;
 }
 
 // The right disparity of (xr, row) over all passes: pass p's keys lie pass_stride floats behind pass p - 1's.
 template <int T>
-__device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, long pass_stride, int n_pass, int xr, int cols, int n_xblocks) {
-    float best = svx_mx_right_key<T>(prow, xr, cols, n_xblocks);
-    for (int p = 1; p < n_pass; ++p) best = fmaxf(best, svx_mx_right_key<T>(prow + p * pass_stride, xr + p * 32 * (T - 1), cols, n_xblocks));
+__device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, long pass_stride, int n_pass, int xr, int cols, int n_groups) {
+    float best = svx_mx_right_key<T>(prow, xr, cols, n_groups);
+    for (int p = 1; p < n_pass; ++p) best = fmaxf(best, svx_mx_right_key<T>(prow + p * pass_stride, xr + p * 32 * (T - 1), cols, n_groups));
     return mx_decode(best);
 }
 
 template <int T>
 __global__ __launch_bounds__(256) void mx_right_view_merge_kernel(const float *__restrict__ partial, long pass_stride, int n_pass, int rows, int cols,
-                                                                  int n_xblocks, float *__restrict__ disp_right_all) {
+                                                                  int n_groups, float *__restrict__ disp_right_all) {
     const int xr = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (xr >= cols) return;
     float *out = disp_right_all + ((long)blockIdx.z * rows + y) * cols;
     if (xr < 2 || xr >= cols - 2 || y < 2 || y >= rows - 2) { out[xr] = 0.0f; return; }
-    const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * 32 * T);
-    out[xr] = svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_xblocks);
+    const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_groups * MxGeom<T>::NKEYS);
+    out[xr] = svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_groups);
 }
 
 // Left-right check straight from the partial keys (the rule of svx_lr_check with the right disparity merged on demand).
 template <int T>
 __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl_all, const float *__restrict__ partial, long pass_stride, int n_pass,
-                                                          int rows, int cols, int n_xblocks, float threshold, float invalid) {
+                                                          int rows, int cols, int n_groups, float threshold, float invalid) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
     float *dl = dl_all + ((long)blockIdx.z * rows + y) * cols;
@@ -622,8 +684,8 @@ __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl
     if (!(d1 >= 0.0f) || !(d1 < (float)cols)) { dl[x] = invalid; return; }       // no disparity (negative, NaN, beyond the row): reads nothing
     const int xr = x - (int)d1;
     if (xr < 2) { dl[x] = invalid; return; }
-    const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_xblocks * 32 * T);
-    if (fabsf(svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_xblocks) - d1) > threshold) dl[x] = invalid;
+    const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_groups * MxGeom<T>::NKEYS);
+    if (fabsf(svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_groups) - d1) > threshold) dl[x] = invalid;
 }
 
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX_M + 4 && rows >= 5 && max_disp >= 1 && max_disp <= MX_MAX_DISP; }
@@ -639,10 +701,12 @@ static MxPlan mx_plan(const svx_ctx *ctx, int max_disp, int words = 2) {
     return {5, (max_disp + 127) / 128};
 }
 static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }
+static int mx_groups(int cols) { return (mx_xblocks(cols) + MX_W - 1) / MX_W; }                 // workgroups along x
+static int mx_keys_per_group(int tiles) { return 32 * (MX_W + tiles - 1); }
 
 size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames, int max_disp) {
     const MxPlan plan = mx_plan(ctx, max_disp);
-    return (size_t)plan.passes * n_frames * rows * mx_xblocks(cols) * 32 * plan.tiles;
+    return (size_t)plan.passes * n_frames * rows * mx_groups(cols) * mx_keys_per_group(plan.tiles);
 }
 
 // Left-view search on two-word descriptors; see svx_dense.hip for the meaning of the arguments.
@@ -656,7 +720,7 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     // number of strips with the smallest (rounds of wavefronts) x (rows a wavefront walks).
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
-    const int n_groups = (mx_xblocks(cols) + MX_W - 1) / MX_W;       // workgroups along x
+    const int n_groups = mx_groups(cols);
     const long slots = (long)cus * ((T <= 5 ? 8 : 4) / MX_W > 0 ? (T <= 5 ? 8 : 4) / MX_W : 1), per_strip = (long)n_groups * n_frames;
     const int out_rows = rows - 4;
     int n_strips = 1;
@@ -672,7 +736,7 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     n_strips = (out_rows + strip_rows - 1) / strip_rows;
     const dim3 grid(n_groups, n_strips, n_frames), block(64 * MX_W);
     const int nb = mx_xblocks(cols);
-    const size_t pass_words = (size_t)n_frames * rows * nb * 32 * T;
+    const size_t pass_words = (size_t)n_frames * rows * n_groups * mx_keys_per_group(T);
     for (int p = 0; p < plan.passes; ++p) {
         const int d_base = p * 32 * (T - 1), flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes ? 2 : 0);
         const int wb = p + 1 == plan.passes ? write_border : 0;
@@ -700,9 +764,9 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
 int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int words, int max_disp,
                         float *disp_left, float *disp_right, float lr_threshold) {
     const dim3 grid(svx_cdiv(cols, 256), rows, n_frames);
-    const int nb = mx_xblocks(cols);
+    const int nb = mx_groups(cols);
     const MxPlan plan = mx_plan(ctx, max_disp, words);
-    const long ps = (long)n_frames * rows * nb * 32 * plan.tiles;
+    const long ps = (long)n_frames * rows * nb * mx_keys_per_group(plan.tiles);
     const int np = plan.passes;
     if (plan.tiles == 9) {
         if (disp_right) mx_right_view_merge_kernel<9><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
