@@ -674,18 +674,28 @@ __global__ __launch_bounds__(256) void mx_right_view_merge_kernel(const float *_
 }
 
 // Left-right check straight from the partial keys (the rule of svx_lr_check with the right disparity merged on demand).
+// One block per row and frame; a thread checks the pixels tid, tid + 256, ... four at a time (their loads are in flight together).
 template <int T>
 __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl_all, const float *__restrict__ partial, long pass_stride, int n_pass,
                                                           int rows, int cols, int n_groups, float threshold, float invalid) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x < 2 || x >= cols - 2 || y < 2 || y >= rows - 2) return;
-    float *dl = dl_all + ((long)blockIdx.z * rows + y) * cols;
-    const float d1 = dl[x];
-    if (!(d1 >= 0.0f) || !(d1 < (float)cols)) { dl[x] = invalid; return; }       // no disparity (negative, NaN, beyond the row): reads nothing
-    const int xr = x - (int)d1;
-    if (xr < 2) { dl[x] = invalid; return; }
-    const float *prow = partial + ((long)blockIdx.z * rows + y) * ((long)n_groups * MxGeom<T>::NKEYS);
-    if (fabsf(svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_groups) - d1) > threshold) dl[x] = invalid;
+    const int y = blockIdx.x + 2;
+    float *dl = dl_all + ((long)blockIdx.y * rows + y) * cols;
+    const float *prow = partial + ((long)blockIdx.y * rows + y) * ((long)n_groups * MxGeom<T>::NKEYS);
+    for (int x0 = 2 + threadIdx.x; x0 < cols - 2; x0 += 4 * 256) {
+        float d1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d1[k] = x0 + 256 * k < cols - 2 ? dl[x0 + 256 * k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + 256 * k;
+            if (x >= cols - 2) break;
+            bool bad = !(d1[k] >= 0.0f) || !(d1[k] < (float)cols);                // no disparity (negative, NaN, beyond the row): reads nothing
+            const int xr = bad ? 0 : x - (int)d1[k];
+            bad = bad || xr < 2;
+            if (!bad) bad = fabsf(svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_groups) - d1[k]) > threshold;
+            if (bad) dl[x] = invalid;
+        }
+    }
 }
 
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX_M + 4 && rows >= 5 && max_disp >= 1 && max_disp <= MX_MAX_DISP; }
@@ -763,20 +773,20 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
 // check of disp_left in place.
 int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int words, int max_disp,
                         float *disp_left, float *disp_right, float lr_threshold) {
-    const dim3 grid(svx_cdiv(cols, 256), rows, n_frames);
+    const dim3 grid(svx_cdiv(cols, 256), rows, n_frames), check_grid(rows - 4, n_frames);
     const int nb = mx_groups(cols);
     const MxPlan plan = mx_plan(ctx, max_disp, words);
     const long ps = (long)n_frames * rows * nb * mx_keys_per_group(plan.tiles);
     const int np = plan.passes;
     if (plan.tiles == 9) {
         if (disp_right) mx_right_view_merge_kernel<9><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
-        else mx_lr_check_kernel<9><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
+        else mx_lr_check_kernel<9><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
     } else if (plan.tiles == 3) {
         if (disp_right) mx_right_view_merge_kernel<3><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
-        else mx_lr_check_kernel<3><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
+        else mx_lr_check_kernel<3><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
     } else {
         if (disp_right) mx_right_view_merge_kernel<5><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
-        else mx_lr_check_kernel<5><<<grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
+        else mx_lr_check_kernel<5><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
     }
     SVX_LAUNCH_CHECK(ctx, "mx right view kernel");
     return SVX_OK;
