@@ -48,10 +48,17 @@ struct MxGeom {
     static constexpr int RPX = 32 * (MX_W + T - 1) + 4;   // right pixels staged per row for the workgroup (2-column window halo each side)
     static constexpr int LPX = 32 * MX_W + 4;
     static constexpr int PX = RPX + LPX;
-    static constexpr int NWORDS = WORDS * PX;              // census words per staged row
-    static constexpr int ROUNDS = (NWORDS + 64 * MX_W - 1) / (64 * MX_W);   // words per thread and row
-    static constexpr int FULL_ROUNDS = NWORDS / (64 * MX_W);                // rounds in which every wavefront takes part
-    static constexpr int ROUND_PX = 64 * MX_W / WORDS;     // pixels a round covers
+    // Staging rounds (every thread takes one census word per round): FR rounds of right words, then FL rounds of left
+    // words, then the words left over, 64 per wavefront: ULT wavefronts' worth of left words followed by URT of right words,
+    // MX_W of them per round.  A wavefront's words of a round thus come from ONE image: their addresses are a scalar row
+    // base plus a 32-bit offset per lane, and whether the leaving row's words are complemented is a scalar.
+    static constexpr int NT = 64 * MX_W;                   // threads
+    static constexpr int RW = WORDS * RPX, LW = WORDS * LPX;
+    static constexpr int FR = RW / NT, FL = LW / NT;
+    static constexpr int ULT = (LW - FL * NT + 63) / 64, URT = (RW - FR * NT + 63) / 64;
+    static constexpr int TAILS = (ULT + URT + MX_W - 1) / MX_W;
+    static constexpr int ROUNDS = FR + FL + TAILS;         // words per thread and row
+    static constexpr int ROUND_PX = NT / WORDS;            // pixels a full round covers
     // LDS image of a staged row, two-word descriptors: one plane per descriptor word (= per k-half of the matrix
     // instruction), a pixel's 32 fp4 values (16 bytes) at [word][pixel], right pixels first.  A 16-lane group of a
     // 16-byte read then covers 256 consecutive bytes (with the two words of a pixel side by side it would hit every
@@ -90,6 +97,12 @@ __device__ __forceinline__ mx_v8i mx_frag(const uint4 v) {
 // two instructions earlier, and the compiler may place a register copy or reload right in front of an asm block: every
 // piece starts with its own padding (measured: no cost).
 #define MX_DPP_GAP() asm volatile("s_nop 1")
+// The vector instructions that read the accumulators are asm blocks, which the compiler does not pad against the
+// matrix instruction that wrote them (an 8-pass result may be read 11 wait states after issue at the earliest).  Inside a
+// row other matrix instructions always lie between a tile's last product and its first reader; where a reader follows the
+// last product directly (the last tile behind the last row of a strip), this padding does: it is tied to the tile's
+// registers, so that no reader is moved in front of it.
+#define MX_MATRIX_RESULT_GAP(tile) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(tile))
 // stage A, pair i: lanes 0..7 of a row (banks 0,1) keep register i, lanes 8..15 register i + 8
 #define MX_RED_A(i) asm volatile("s_nop 1\n\t"                                                       \
                                  "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
@@ -129,6 +142,13 @@ constexpr int mx_unit_step(int v) { return 1 + v * (mx_meet_step<T, PER>() - MX_
 
 // Where the operands of a row are: two-word descriptors read the entering and the leaving image at this lane's pixel;
 // with one-word descriptors each of the five instructions of a tile has a read position of its own (cur[j], nxt[j]).
+// Where the staging of a row fetches from: the strip's census rows of either image as buffer resources (scalar), and the
+// byte offsets of the row after next (entering) and of the one three rows up (leaving) in them.  A lane adds its 32-bit
+// offset inside the row: no lane forms a 64-bit address.
+struct MxRows { __amdgpu_buffer_rsrc_t left, right; uint32_t off_new, off_old; };
+__device__ __forceinline__ uint32_t mx_word(__amdgpu_buffer_rsrc_t image, uint32_t row_off, uint32_t byte_off) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(image, byte_off, row_off, 0);
+}
 template <int WORDS> struct MxPtrs;
 template <> struct MxPtrs<2> { const uint4 *cur_e, *cur_l, *nxt_e; };
 template <> struct MxPtrs<1> { const uint4 *cur[5], *nxt[5]; };
@@ -137,14 +157,15 @@ template <int T>
 struct MxState {
     using G = MxGeom<T, 2>;                                  // (sized for two-word descriptors; one-word ones use fewer rounds)
     uint32_t wn[G::ROUNDS], wo[G::ROUNDS];                   // census words of the next row to stage (entering, leaving)
-    const uint32_t *src[G::ROUNDS];                          // this thread's word of staging round i in census row 0 of the strip
-    uint32_t flip[G::ROUNDS];                                // all ones where that word is a left word
-    int slot0;                                               // where this thread's word of round 0 goes in a staged row (round i: + ROUND_PX i)
+    uint32_t voff[G::ROUNDS];                                // byte offset of this thread's word of staging round i in a census row
+    int slot0;                                               // where this thread's word of a full round goes in a staged row (+ a constant per round)
+    int slot_t[2];                                           // the same for the rounds of left-over words, which differ from wavefront to wavefront
+    bool t_any[2], t_left[2], t_has[2];                      // those rounds: this wavefront takes part / stages left words / this lane holds a word
     bool own;                                                // this lane's left column belongs to this x-block alone (the last block is shifted over its neighbour)
-    bool tail_wave, tail_lane;                               // last, partial round: this wavefront takes part / this lane holds a word
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
     float pen_l[T], pen_r[16];                               // border blocks: what each view must not use (0 or -2^21)
-    float *out;                                              // left map: this lane's pixel of the row being written
+    float *out_row;                                          // left map: the x-block's first pixel of the row being written (the same for every lane) ...
+    uint32_t out_off;                                        // ... and this lane's byte offset from it
     long out_stride;
     // right view (see mx_keys_flush)
     float *key0;                                             // this lane's slot for tile 0 in key row 0 (LDS)
@@ -152,7 +173,8 @@ struct MxState {
     float *kflush0;                                          // this thread's first key of key row 0
     int krow;                                                // key row being filled
     float kv[G::KEY_ROUNDS];                                 // keys on their way out
-    float *part;                                             // where this thread's first key of the next finished row goes
+    float *part_row;                                         // where the workgroup's keys of the next finished row go (the same for every thread; thread tid's first key 4 tid bytes behind)
+    uint32_t tid4;
     long part_stride;
 };
 
@@ -186,9 +208,11 @@ __device__ __forceinline__ void mx_right_b(const mx_v16f (&acc)[T], const MxStat
 }
 // Both lane halves hold left columns of the same right column; the workgroup's other x-blocks cover it as well: all of
 // them meet in the key row (a 4-byte LDS operation serves the two halves in different cycles, so equal addresses do not collide).
-template <int T, int U>
+// KROW: the key row when the caller knows it at compile time (the address is then a constant offset), -1: the one st.kcur points to.
+template <int T, int U, int KROW = -1>
 __device__ __forceinline__ void mx_right_c(MxState<T> &st, const float (&x)[5]) {
-    __hip_atomic_fetch_max(st.kcur + U * 32, x[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    float *const p = KROW < 0 ? st.kcur + U * 32 : st.key0 + KROW * MxState<T>::G::NKEYS + U * 32;
+    __hip_atomic_fetch_max(p, x[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // The next output row's keys go to the next key row.
 template <int T>
@@ -200,24 +224,24 @@ __device__ __forceinline__ void mx_keys_next_row(MxState<T> &st) {
 // every wavefront has passed the meeting point of the census row after it (its last tile is read during that row's first
 // products): the row is written out behind that point, while the wavefronts fill the row after it and, those that are ahead,
 // the one after that, which is why three key rows are in use.  Key row `which` (0: the one being filled, MX_KROWS - 1: the one before it).
-template <int T>
+template <int T, int KROW = -1>
 __device__ __forceinline__ void mx_keys_flush_read(MxState<T> &st, int which) {
     using G = typename MxState<T>::G;
-    const int kr = st.krow + which >= MX_KROWS ? st.krow + which - MX_KROWS : st.krow + which;
+    const int kr = KROW >= 0 ? KROW : st.krow + which >= MX_KROWS ? st.krow + which - MX_KROWS : st.krow + which;
 #pragma unroll
     for (int i = 0; i < G::KEY_ROUNDS; ++i) st.kv[i] = st.kflush0[kr * G::NKEYS + i * 64 * MX_W];   // (a thread without a key in the last round reads inside the LDS block)
 }
-template <int T>
+template <int T, int KROW = -1>
 __device__ __forceinline__ void mx_keys_flush_write(MxState<T> &st, int which, int tid) {
     using G = typename MxState<T>::G;
-    const int kr = st.krow + which >= MX_KROWS ? st.krow + which - MX_KROWS : st.krow + which;
+    const int kr = KROW >= 0 ? KROW : st.krow + which >= MX_KROWS ? st.krow + which - MX_KROWS : st.krow + which;
 #pragma unroll
     for (int i = 0; i < G::KEY_ROUNDS; ++i)
         if ((i + 1) * 64 * MX_W <= G::NKEYS || tid + i * 64 * MX_W < G::NKEYS) {
-            st.part[i * 64 * MX_W] = st.kv[i];
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(st.part_row + i * 64 * MX_W) + st.tid4) = st.kv[i];
             st.kflush0[kr * G::NKEYS + i * 64 * MX_W] = MX_NO_KEY;
         }
-    st.part += st.part_stride;
+    st.part_row += st.part_stride;
 }
 
 // Decodes the winner of a left pixel: key = window score + (1023 - d) / 1024; an inadmissible pair sits near -2^20.
@@ -242,8 +266,9 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane, int pas
     const float zo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, z), 0x401f));   // lane ^ 16
     z = mx_max(z, zo);
     if (st.own) {                                            // (a column that two x-blocks cover is written by one of them: with passes the map is read back)
-        if (pass_flags & 1) z = mx_max(z, *st.out);
-        *st.out = (pass_flags & 2) ? z : mx_decode(z);       // lanes l and l ^ 16 write the same value to the same place
+        float *const out = reinterpret_cast<float *>(reinterpret_cast<char *>(st.out_row) + st.out_off);
+        if (pass_flags & 1) z = mx_max(z, *out);
+        *out = (pass_flags & 2) ? z : mx_decode(z);          // lanes l and l ^ 16 write the same value to the same place
     }
 }
 
@@ -264,9 +289,9 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane, int pas
 // ten window pixels of the entering and the leaving row make five instructions, (e0,e1) (e2,e3) (e4,l0) (l1,l2) (l3,l4),
 // each with its own per-lane read position.  Before the steady state the leaving pixels are not there yet: the fourth
 // and fifth instruction are skipped and the third multiplies its second half by zero.
-template <int T, int WORDS, bool STEADY, bool BOTH, bool EDGE>
+template <int T, int WORDS, bool STEADY, bool BOTH, bool EDGE, int KR = -1>
 __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &ptr, uint4 *stage_e, uint4 *stage_l, MxState<T> &st,
-                                       mx_v8i (&an)[5], uint4 (&fb)[MX_P], long off_new, long off_old, int lane, int tid, int pass_flags) {
+                                       mx_v8i (&an)[5], uint4 (&fb)[MX_P], const MxRows &rows_g, int lane, int tid, int pass_flags) {
     using G = MxGeom<T, WORDS>;
     constexpr int PER = WORDS == 2 && STEADY ? 10 : 5, S = T * PER, P = MX_P;
     constexpr int MEET = mx_meet_step<T, PER>();
@@ -315,19 +340,32 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
             if constexpr (mx_unit_step<T, WORDS, PER>(v) == s && !(MX_X & 1)) {
                 constexpr bool old = v >= G::ROUNDS;                  // entering row first, then the leaving row
                 constexpr int i = old ? v - G::ROUNDS : v;
-                auto unit = [&](bool lane_has_word) __attribute__((always_inline)) {
+                constexpr int kind = i < G::FR ? 0 : i < G::FR + G::FL ? 1 : 2;     // right words, left words, left-over words
+                constexpr int kt = kind == 2 ? i - G::FR - G::FL : 0;
+                auto unit = [&]() __attribute__((always_inline)) {
                     uint32_t w = old ? st.wo[i] : st.wn[i];
-                    if constexpr (old) w ^= st.flip[i];               // the leaving row's left words are complemented
+                    if constexpr (old) {                               // the leaving row's left words are complemented
+                        if constexpr (kind == 1) w = ~w;
+                        else if constexpr (kind == 2) w ^= st.t_left[kt] ? 0xffffffffu : 0u;
+                    }
                     uint4 e;
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.x) : "v"(w << 3), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.y) : "v"(w << 2), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.z) : "v"(w << 1), "s"(m88), "v"(c22));
                     asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e.w) : "v"(w), "s"(m88), "v"(c22));
-                    if (lane_has_word) (old ? stage_l : stage_e)[st.slot0 + i * G::ROUND_PX] = e;
-                    if constexpr (old) st.wo[i] = st.src[i][off_old]; else st.wn[i] = st.src[i][off_new];
+                    uint4 *const img = old ? stage_l : stage_e;
+                    if constexpr (kind == 0) img[st.slot0 + i * G::ROUND_PX] = e;
+                    else if constexpr (kind == 1) img[st.slot0 + G::RPX + (i - G::FR) * G::ROUND_PX] = e;
+                    else if (st.t_has[kt]) img[st.slot_t[kt]] = e;
+                    const uint32_t row_off = old ? rows_g.off_old : rows_g.off_new;
+                    uint32_t x;
+                    if constexpr (kind == 0) x = mx_word(rows_g.right, row_off, st.voff[i]);
+                    else if constexpr (kind == 1) x = mx_word(rows_g.left, row_off, st.voff[i]);
+                    else x = st.t_left[kt] ? mx_word(rows_g.left, row_off, st.voff[i]) : mx_word(rows_g.right, row_off, st.voff[i]);
+                    if constexpr (old) st.wo[i] = x; else st.wn[i] = x;
                 };
-                if constexpr (i < G::FULL_ROUNDS) unit(true);
-                else if (st.tail_wave) unit(st.tail_lane);
+                if constexpr (kind < 2) unit();
+                else if (st.t_any[kt]) unit();
             }
         });
 
@@ -364,15 +402,17 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
             if constexpr (t == 2 && j == 0) { MX_RED_B(0); MX_RED_B(1); }
             if constexpr (t == 2 && j == 1) { MX_RED_B(2); MX_RED_B(3); }
             if constexpr (t == 2 && j == 2) { MX_RED_C(); }
-            if constexpr (t == 2 && j == 3) { mx_reduce_tail<T>(st, lane, pass_flags); st.out += st.out_stride; }
+            if constexpr (t == 2 && j == 3) { mx_reduce_tail<T>(st, lane, pass_flags); st.out_row += st.out_stride; }
             // right view: tile t - 1 of this row, or the last tile of the previous row
             if constexpr (BOTH) {
                 constexpr int u = t == 0 ? T - 1 : t - 1;
                 if constexpr (j == 4) mx_right_a<T, EDGE, u>(acc, st, rx);
                 if constexpr (j == 8) mx_right_b<T, EDGE, u>(acc, st, rx);
                 if constexpr (j == 9) {
-                    mx_right_c<T, u>(st, rx);
-                    if constexpr (t == 0) mx_keys_next_row<T>(st);    // the following tiles belong to this row
+                    if constexpr (KR < 0) {
+                        mx_right_c<T, u>(st, rx);
+                        if constexpr (t == 0) mx_keys_next_row<T>(st);    // the following tiles belong to this row
+                    } else mx_right_c<T, u, (t == 0 ? KR : (KR + 1) % MX_KROWS)>(st, rx);
                 }
             }
         };
@@ -380,8 +420,8 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
             if constexpr (PER == 10) select(std::integral_constant<int, j>{});
             else { select(std::integral_constant<int, 2 * j>{}); select(std::integral_constant<int, 2 * j + 1>{}); }
             if constexpr (BOTH) {                            // every wavefront has passed the meeting point: the previous output row's keys are complete
-                if constexpr (s == MEET + 1) mx_keys_flush_read<T>(st, MX_KROWS - 1);
-                if constexpr (s == MEET + 3) mx_keys_flush_write<T>(st, MX_KROWS - 1, tid);
+                if constexpr (s == MEET + 1) mx_keys_flush_read<T, KR>(st, MX_KROWS - 1);
+                if constexpr (s == MEET + 3) mx_keys_flush_write<T, KR>(st, MX_KROWS - 1, tid);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -411,7 +451,8 @@ __device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState
 
 // After the last row of a strip: its last tile, the lane reduction and the stores (nothing follows to hide them behind).
 template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_last_output(const mx_v16f (&acc)[T], MxState<T> &st, int lane, int tid, int pass_flags) {
+__device__ __forceinline__ void mx_last_output(mx_v16f (&acc)[T], MxState<T> &st, int lane, int tid, int pass_flags) {
+    MX_MATRIX_RESULT_GAP(acc[T - 1]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (T == 5) st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, 3, i));
@@ -473,28 +514,49 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.pen_r[i] = xl0 + (i & 3) + 8 * (i >> 2) + 4 * h <= cols - 6 ? 0.0f : -2097152.0f;
 
-    // staging: word q of a staged row is right word (xl0_wg - 32 (T - 1) - d_base - 2) * WORDS + q for q < WORDS RPX, left
-    // word (xl0_wg - 2) * WORDS + q - WORDS RPX after it; thread tid takes the words tid, tid + 256, ...  Words outside the
-    // frame are clamped into it: left of the frame they only feed inadmissible pairs, right of it (the columns behind the
-    // last x-block of a workgroup that the frame does not fill) nothing reads them.
+    // staging (rounds: MxGeom): right word q of a staged row is word (xl0_wg - 32 (T - 1) - d_base - 2) * WORDS + q of the right
+    // census row, left word q is word (xl0_wg - 2) * WORDS + q of the left one.  Words outside the frame are clamped into it:
+    // left of the frame they only feed inadmissible pairs, right of it (the columns behind the last x-block of a workgroup
+    // that the frame does not fill) nothing reads them.
     const long row_words = (long)cols * WORDS;
     const uint32_t *const cl0 = cl + (long)(y_lo - 2) * row_words, *const cr0 = cr + (long)(y_lo - 2) * row_words;
+    const uint32_t row_bytes = 4u * (uint32_t)row_words;
+    MxRows rg;
+    rg.left = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cl0), 0, (int)(row_bytes * (uint32_t)n_rows), 0x00020000);
+    rg.right = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cr0), 0, (int)(row_bytes * (uint32_t)n_rows), 0x00020000);
+    auto right_off = [&](int q) -> uint32_t { return 4u * (uint32_t)min(max((long)(xl0_wg - 32 * (T - 1) - d_base - 2) * WORDS + q, 0L), row_words - 1); };
+    auto left_off = [&](int q) -> uint32_t { return 4u * (uint32_t)min(max((long)(xl0_wg - 2) * WORDS + q, 0L), row_words - 1); };
+    auto slot_of = [&](int q, bool left) -> int { return WORDS == 2 ? (q & 1) * G::PLANE + (left ? G::RPX : 0) + (q >> 1) : (left ? G::RPX : 0) + q; };
 #pragma unroll
-    for (int i = 0; i < G::ROUNDS; ++i) {
-        const int q = min(i * (64 * MX_W) + tid, G::NWORDS - 1);
-        const bool is_left = q >= WORDS * G::RPX;
-        const long wr = min(max((long)(xl0_wg - 32 * (T - 1) - d_base - 2) * WORDS + q, 0L), row_words - 1);
-        const long wl = min(max((long)(xl0_wg - 2) * WORDS + (q - WORDS * G::RPX), 0L), row_words - 1);
-        st.src[i] = is_left ? cl0 + wl : cr0 + wr;
-        st.flip[i] = is_left ? 0xffffffffu : 0u;
+    for (int i = 0; i < G::FR; ++i) st.voff[i] = right_off(i * G::NT + tid);
+#pragma unroll
+    for (int i = 0; i < G::FL; ++i) st.voff[G::FR + i] = left_off(i * G::NT + tid);
+    st.slot0 = slot_of(tid, false);
+#pragma unroll
+    for (int k = 0; k < G::TAILS; ++k) {
+        const int v = k * MX_W + wave;               // this wavefront's unit of left-over words: ULT units of left words, then URT of right words
+        const bool left = v < G::ULT;
+        const int q = left ? G::FL * G::NT + 64 * v + lane : G::FR * G::NT + 64 * (v - G::ULT) + lane;
+        st.t_any[k] = v < G::ULT + G::URT;
+        st.t_left[k] = left;
+        st.t_has[k] = q < (left ? G::LW : G::RW);
+        st.slot_t[k] = slot_of(min(q, (left ? G::LW : G::RW) - 1), left);
+        st.voff[G::FR + G::FL + k] = left ? left_off(q) : right_off(q);
     }
-    auto word = [&](int i, int r) -> uint32_t { return st.src[i][r * row_words]; };   // word of staging round i in census row r of the strip
-    st.slot0 = WORDS == 2 ? (tid & 1) * G::PLANE + (tid >> 1) : tid;
-    st.tail_wave = (G::ROUNDS - 1) * (64 * MX_W) + wave * 64 < G::NWORDS;
-    st.tail_lane = (G::ROUNDS - 1) * (64 * MX_W) + tid < G::NWORDS;
+    // word of staging round i in census row r of the strip
+    auto word = [&](int i, int r) -> uint32_t {
+        const bool left = i < G::FR ? false : i < G::FR + G::FL ? true : st.t_left[i - G::FR - G::FL];
+        return left ? mx_word(rg.left, r * row_bytes, st.voff[i]) : mx_word(rg.right, r * row_bytes, st.voff[i]);
+    };
+    auto put0 = [&](int i, uint4 e) {                // round i's word into the first staged row
+        if (i < G::FR) lds[st.slot0 + i * G::ROUND_PX] = e;
+        else if (i < G::FR + G::FL) lds[st.slot0 + G::RPX + (i - G::FR) * G::ROUND_PX] = e;
+        else if (st.t_any[i - G::FR - G::FL] && st.t_has[i - G::FR - G::FL]) lds[st.slot_t[i - G::FR - G::FL]] = e;
+    };
     const int last = n_rows - 1;
     const int i_out = lane & 15;
-    st.out = disp + (long)y_lo * cols + xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h;
+    st.out_row = disp + (long)y_lo * cols + xl0;
+    st.out_off = 4u * (uint32_t)((i_out & 3) + 8 * (i_out >> 2) + 4 * h);
     st.own = xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h >= own_from;
     st.out_stride = cols;
     if (BOTH) {
@@ -505,7 +567,8 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         st.kcur = st.key0;
         st.krow = 0;
         st.kflush0 = keys + tid;
-        st.part = part_row0 + tid;
+        st.part_row = part_row0;
+        st.tid4 = 4u * (uint32_t)tid;
         st.part_stride = part_stride;
     }
 
@@ -537,7 +600,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
 #pragma unroll
         for (int i = 0; i < G::ROUNDS; ++i)
-            if (i < G::FULL_ROUNDS || st.tail_lane) img_e(0)[st.slot0 + i * G::ROUND_PX] = mx_expand(word(i, 0), c22);
+            put0(i, mx_expand(word(i, 0), c22));
 #pragma unroll
         for (int i = 0; i < G::ROUNDS; ++i) { st.wn[i] = word(i, 1); st.wo[i] = 0u; }
     }
@@ -556,20 +619,51 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     // row r stages row r+1 (entering) with row r-4 (leaving) and fetches the words of rows r+2 and r-3
 #pragma unroll 1
     for (int r = 0; r < 5; ++r) {
-        const long on = (long)min(r + 2, last) * row_words, oo = (long)max(r - 3, 0) * row_words;
-        mx_row<T, WORDS, false, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, tid, pass_flags);
+        rg.off_new = (uint32_t)min(r + 2, last) * row_bytes;
+        rg.off_old = (uint32_t)max(r - 3, 0) * row_bytes;
+        mx_row<T, WORDS, false, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, rg, lane, tid, pass_flags);
         b_cur = b_nxt;
         b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
         point(b_cur, b_nxt);
     }
     mx_first_output<T, BOTH, EDGE>(acc, st);
+    // Steady state, three rows per trip: census row r reads staged image r % 3 and writes image (r + 1) % 3, and the keys of
+    // the output row that ends with it go to key row (r + 1) % 3, so with the phase of a row a compile-time constant every
+    // LDS address of the row is a constant offset from a register that never changes.
+    static_assert(MX_NBUF == 3 && MX_KROWS == 3, "the steady state is unrolled over three rows");
+    auto steady = [&](auto b_c, int r) __attribute__((always_inline)) {
+        constexpr int B = decltype(b_c)::value, N = (B + 1) % MX_NBUF;
+        rg.off_new = (uint32_t)min(r + 2, last) * row_bytes;
+        rg.off_old = (uint32_t)(r - 3) * row_bytes;
+        point(B, N);
+        mx_row<T, WORDS, true, BOTH, EDGE, N>(acc, ptr, img_e(N), img_l(N), st, an, fb, rg, lane, tid, pass_flags);
+    };
+    if constexpr (T <= 5) {
+        int r = 5;
 #pragma unroll 1
-    for (int r = 5; r < n_rows; ++r) {
-        const long on = (long)min(r + 2, last) * row_words, oo = (long)(r - 3) * row_words;
-        mx_row<T, WORDS, true, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, on, oo, lane, tid, pass_flags);
-        b_cur = b_nxt;
-        b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
-        point(b_cur, b_nxt);
+        for (; r + 3 <= n_rows; r += 3) {
+            steady(std::integral_constant<int, 2>{}, r);
+            steady(std::integral_constant<int, 0>{}, r + 1);
+            steady(std::integral_constant<int, 1>{}, r + 2);
+        }
+        if (r < n_rows) {
+            steady(std::integral_constant<int, 2>{}, r);
+            if (r + 1 < n_rows) steady(std::integral_constant<int, 0>{}, r + 1);
+        }
+        if (BOTH) {                                  // the key row the last output row's keys are in
+            st.krow = (n_rows - 5) % MX_KROWS;
+            st.kcur = st.key0 + st.krow * G::NKEYS;
+        }
+    } else {                                         // (nine tiles: the constant addresses of three unrolled rows do not fit in the registers)
+#pragma unroll 1
+        for (int r = 5; r < n_rows; ++r) {
+            rg.off_new = (uint32_t)min(r + 2, last) * row_bytes;
+            rg.off_old = (uint32_t)(r - 3) * row_bytes;
+            mx_row<T, WORDS, true, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, rg, lane, tid, pass_flags);
+            b_cur = b_nxt;
+            b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
+            point(b_cur, b_nxt);
+        }
     }
     mx_last_output<T, BOTH, EDGE>(acc, st, lane, tid, pass_flags);
 }
