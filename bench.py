@@ -296,8 +296,8 @@ def main():
         # both-views sweep the right view's partial minima (80 words per output row, 16-column block and 64-disparity chunk)
         kernel_name = S.dense_kernel_name(rows, cols, words, D, both_views, ctx)
         on_matrix_cores = kernel_name == "dense_wta_mx_kernel"
-        if on_matrix_cores:      # 32 keys per tile of right columns, output row and 32-column block
-            part_bytes = 4.0 * 32 * (3 if D <= 64 else 5) * max(1, -(-D // 128)) * F * (rows - 4) * ((cols - 4 + 31) // 32) if both_views else 0.0
+        if on_matrix_cores:      # one key per right column a workgroup (four 32-column blocks) covers, per output row and pass of 128 disparities
+            part_bytes = 4.0 * 32 * (4 + (3 if D <= 64 else 5) - 1) * max(1, -(-D // 128)) * F * (rows - 4) * -(-((cols - 4 + 31) // 32) // 4) if both_views else 0.0
         else:
             part_bytes = 4.0 * 80 * F * (rows - 4) * ((cols - 4 + 15) // 16) * ((D + 63) // 64) if both_views else 0.0
         kernel_io_bytes = float(rows * cols * F * (2 * 4 * words + 4)) + part_bytes     # what this kernel itself must move
@@ -362,7 +362,7 @@ def main():
             # The headline stays the vector-popcount floor (one xor + one popcount per descriptor word and pix*disp), the
             # pricing every kernel choice shares; the matrix work this kernel really issues is reported beside it.
             roofline["mfma"] = {
-                "instruction": "v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 operands, unit scales)",
+                "instruction": "v_mfma_f32_32x32x64_f8f6f4 (fp4 operands, the form without scale operands)",
                 "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "issued_flops_per_launch": issued_flops, "issued_achieved": round(issued_flops / (k_ms * 1e-3) / 1e12, 1),
                 "issued_frac": round(issued_flops / (k_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4),
