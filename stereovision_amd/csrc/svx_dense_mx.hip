@@ -374,28 +374,31 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
             constexpr int j = decltype(j_c)::value;
             // left view
             // (five tiles: two three-way maxima per element; fewer tiles: tile by tile)
+            // (a tile is first read from slot 2 on, i.e. behind at least two matrix instructions after its last product:
+            // the readers are asm blocks, which the compiler does not pad against the matrix instruction, see MX_MATRIX_RESULT_GAP)
+            constexpr int e = 2 * (j - 2);                             // slots 2 .. 9 take two accumulator elements each
             if constexpr (T == 5) {
-                if constexpr (t == 0 && j < 8) {                       // tiles 3 and 4 of the previous row
-                    st.best[2 * j] = mx_max3(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, 3, 2 * j), mx_elem_l<T, EDGE>(acc, st, 4, 2 * j));
-                    st.best[2 * j + 1] = mx_max3(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, 3, 2 * j + 1), mx_elem_l<T, EDGE>(acc, st, 4, 2 * j + 1));
+                if constexpr (t == 0 && j >= 2) {                      // tiles 3 and 4 of the previous row
+                    st.best[e] = mx_max3(st.best[e], mx_elem_l<T, EDGE>(acc, st, 3, e), mx_elem_l<T, EDGE>(acc, st, 4, e));
+                    st.best[e + 1] = mx_max3(st.best[e + 1], mx_elem_l<T, EDGE>(acc, st, 3, e + 1), mx_elem_l<T, EDGE>(acc, st, 4, e + 1));
                 }
-                if constexpr (t == 3 && j < 8) {                       // tiles 0, 1 and 2 of this row
-                    st.best[2 * j] = mx_max3(mx_elem_l<T, EDGE>(acc, st, 0, 2 * j), mx_elem_l<T, EDGE>(acc, st, 1, 2 * j), mx_elem_l<T, EDGE>(acc, st, 2, 2 * j));
-                    st.best[2 * j + 1] = mx_max3(mx_elem_l<T, EDGE>(acc, st, 0, 2 * j + 1), mx_elem_l<T, EDGE>(acc, st, 1, 2 * j + 1), mx_elem_l<T, EDGE>(acc, st, 2, 2 * j + 1));
+                if constexpr (t == 3 && j >= 2) {                      // tiles 0, 1 and 2 of this row
+                    st.best[e] = mx_max3(mx_elem_l<T, EDGE>(acc, st, 0, e), mx_elem_l<T, EDGE>(acc, st, 1, e), mx_elem_l<T, EDGE>(acc, st, 2, e));
+                    st.best[e + 1] = mx_max3(mx_elem_l<T, EDGE>(acc, st, 0, e + 1), mx_elem_l<T, EDGE>(acc, st, 1, e + 1), mx_elem_l<T, EDGE>(acc, st, 2, e + 1));
                 }
             } else {
-                if constexpr (t == 0 && j < 8) {                       // last tile of the previous row
-                    st.best[2 * j] = mx_max(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, T - 1, 2 * j));
-                    st.best[2 * j + 1] = mx_max(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, T - 1, 2 * j + 1));
+                if constexpr (t == 0 && j >= 2) {                      // last tile of the previous row
+                    st.best[e] = mx_max(st.best[e], mx_elem_l<T, EDGE>(acc, st, T - 1, e));
+                    st.best[e + 1] = mx_max(st.best[e + 1], mx_elem_l<T, EDGE>(acc, st, T - 1, e + 1));
                 }
                 if constexpr (t == 2 && j >= 5 && j < 9) {             // tiles 0 and 1 of this row
 #pragma unroll
                     for (int i = 4 * (j - 5); i < 4 * (j - 5) + 4; ++i)
                         st.best[i] = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
                 }
-                if constexpr (t >= 3 && j < 8) {                       // tile t - 1 of this row
-                    st.best[2 * j] = mx_max(st.best[2 * j], mx_elem_l<T, EDGE>(acc, st, t - 1, 2 * j));
-                    st.best[2 * j + 1] = mx_max(st.best[2 * j + 1], mx_elem_l<T, EDGE>(acc, st, t - 1, 2 * j + 1));
+                if constexpr (t >= 3 && j >= 2) {                      // tile t - 1 of this row
+                    st.best[e] = mx_max(st.best[e], mx_elem_l<T, EDGE>(acc, st, t - 1, e));
+                    st.best[e + 1] = mx_max(st.best[e + 1], mx_elem_l<T, EDGE>(acc, st, t - 1, e + 1));
                 }
             }
             if constexpr (t == 1 && j < 8) { MX_RED_A(j); }
