@@ -73,13 +73,15 @@ int svx_synchronize(svx_ctx *ctx);
  *   SVX_OPT_MESH_ON_DEVICE   (SVX_MESH_ON_DEVICE)  0 = svx_high_perf_stereo triangulates its support points on the host
  *                                                  (svx_mesh_*); default 1 = on the device (svx_mesh_plane_prior_device);
  *                                                  the triangles are the same
+ *   SVX_OPT_SUBPIXEL_TILES   (SVX_SUBPIXEL_TILES)  0 = the sub-pixel step reads every descriptor from memory; default 1 = the left
+ *                                                  descriptors of a block of pixels are staged in LDS
  * The one option that changes results:
  *   SVX_OPT_PRIOR_BAND_RADIUS (SVX_PRIOR_BAND_RADIUS) radius of svx_high_perf_stereo's search around the plane prior
  *                                                  (svx_cost_eval_band); default 0 = the reference's single disparity */
 enum svx_option {
     SVX_OPT_MATRIX_CORES = 0, SVX_OPT_LR_TWO_SWEEPS = 1, SVX_OPT_SWEEP_WAVES = 2, SVX_OPT_SWEEP_WAVES_BOTH = 3,
     SVX_OPT_CENSUS97_PACKED = 4, SVX_OPT_MX_STRIP_ROWS = 5, SVX_OPT_STAGE_TIMES = 6, SVX_OPT_PRIOR_BAND_RADIUS = 7, SVX_OPT_MX_WIDE_TILES = 8,
-    SVX_OPT_MESH_ON_DEVICE = 9, SVX_OPT_COUNT = 10
+    SVX_OPT_MESH_ON_DEVICE = 9, SVX_OPT_SUBPIXEL_TILES = 10, SVX_OPT_COUNT = 11
 };
 int svx_set_option(svx_ctx *ctx, int option, int value);
 int svx_get_option(const svx_ctx *ctx, int option, int *value);   /* ctx NULL: the default a new context would get */

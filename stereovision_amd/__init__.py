@@ -29,6 +29,7 @@ from ._lib import (  # noqa: F401
     OPT_PRIOR_BAND_RADIUS,
     OPT_MX_WIDE_TILES,
     OPT_MESH_ON_DEVICE,
+    OPT_SUBPIXEL_TILES,
     EXPORTS,
     DOMINANT_KERNEL,
     dense_kernel_name,

@@ -10,7 +10,7 @@ EXFAST_NONMAX, EXFAST_THRESHOLD_ROUND_SAT = 1, 2
 VIEW_LEFT, VIEW_RIGHT = 0, 1
 WINDOW_5X6, WINDOW_5X5 = 0, 1
 # svx_option of include/svx.h
-OPT_MATRIX_CORES, OPT_LR_TWO_SWEEPS, OPT_SWEEP_WAVES, OPT_SWEEP_WAVES_BOTH, OPT_CENSUS97_PACKED, OPT_MX_STRIP_ROWS, OPT_STAGE_TIMES, OPT_PRIOR_BAND_RADIUS, OPT_MX_WIDE_TILES, OPT_MESH_ON_DEVICE = range(10)
+OPT_MATRIX_CORES, OPT_LR_TWO_SWEEPS, OPT_SWEEP_WAVES, OPT_SWEEP_WAVES_BOTH, OPT_CENSUS97_PACKED, OPT_MX_STRIP_ROWS, OPT_STAGE_TIMES, OPT_PRIOR_BAND_RADIUS, OPT_MX_WIDE_TILES, OPT_MESH_ON_DEVICE, OPT_SUBPIXEL_TILES = range(11)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _vp = C.c_void_p

@@ -262,7 +262,10 @@ SUBPIXEL_TOL = 1e-3   # px, the tolerance required of sub-pixel disparities; the
 
 @pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (30, 150, 128), (9, 21, 5), (5, 20, 8), (64, 300, 200), (4, 30, 4)])
 @pytest.mark.parametrize("words", [1, 2])
-def test_subpixel_refine_matches_oracle(ctx, rows, cols, max_disp, words):
+@pytest.mark.parametrize("tiles", [1, 0])
+def test_subpixel_refine_matches_oracle(ctx, rows, cols, max_disp, words, tiles):
+    """Both forms of the step: the left descriptors of a block staged in LDS (the default) and every descriptor from memory."""
+    import stereovision_amd as S
     rng = np.random.default_rng(rows * 7 + cols + words)
     shape = (2, rows, cols) + ((2,) if words == 2 else ())
     cl = rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32)
@@ -274,7 +277,11 @@ def test_subpixel_refine_matches_oracle(ctx, rows, cols, max_disp, words):
     disp[(mask >= 0.05) & (mask < 0.10)] += 0.25
     disp[(mask >= 0.10) & (mask < 0.15)] = float(max_disp - 1)
     disp[(mask >= 0.15) & (mask < 0.20)] = rng.integers(0, max_disp, size=int(((mask >= 0.15) & (mask < 0.20)).sum()))
-    got = ctx.subpixel_refine(dev_u32(cl), dev_u32(cr), max_disp, dev(disp), words=words).cpu().numpy()
+    ctx.set_option(S.OPT_SUBPIXEL_TILES, tiles)
+    try:
+        got = ctx.subpixel_refine(dev_u32(cl), dev_u32(cr), max_disp, dev(disp), words=words).cpu().numpy()
+    finally:
+        ctx.set_option(S.OPT_SUBPIXEL_TILES, 1)
     changed = 0
     for f in range(2):
         want = O.subpixel_refine(cl[f], cr[f], max_disp, disp[f])
