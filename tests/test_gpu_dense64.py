@@ -256,6 +256,37 @@ def test_fused_census9x7_lr(ctx, rows, cols, max_disp, thr):
     assert (np.abs(want - field)[valid & interior] <= 1).mean() > 0.9
 
 
+@pytest.mark.parametrize("strip_rows", [1, 2, 6, 7, 8, 9])
+@pytest.mark.parametrize("D,words", [(40, 2), (100, 2), (200, 2), (100, 1), (40, 1)])
+def test_matrix_search_strip_lengths(ctx, strip_rows, D, words):
+    """The steady state of the matrix-core search runs three rows per trip with a remainder of 0, 1 or 2 rows, and strips
+    of fewer than two output rows have no steady row at all: every remainder, with strips forced short so that a frame
+    has many strip ends, both views, against the vector sweep."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    rows, cols = 61, 300
+    ls, rs = synth.stereo_batch(rows, cols, D, 2, seed0=31 + D + strip_rows)
+    if words == 2:
+        cl, cr = ctx.census9x7(dev(ls)), ctx.census9x7(dev(rs))
+    else:
+        cl, cr = ctx.census5x5(dev(ls)), ctx.census5x5(dev(rs))
+    ctx.set_option(S.OPT_MATRIX_CORES, 0)
+    try:
+        wl = ctx.dense_wta(cl, cr, D, S.VIEW_LEFT, words)
+        wr = ctx.dense_wta(cl, cr, D, S.VIEW_RIGHT, words)
+    finally:
+        ctx.set_option(S.OPT_MATRIX_CORES, -1)
+    ctx.set_option(S.OPT_MX_STRIP_ROWS, strip_rows)
+    try:
+        ml, mr = ctx.dense_wta_both(cl, cr, D, words)
+        ml0 = ctx.dense_wta(cl, cr, D, S.VIEW_LEFT, words)
+    finally:
+        ctx.set_option(S.OPT_MX_STRIP_ROWS, 0)
+    assert torch.equal(ml, wl), (ml != wl).nonzero()[:5].tolist()
+    assert torch.equal(ml0, wl), (ml0 != wl).nonzero()[:5].tolist()
+    assert torch.equal(mr, wr), (mr != wr).nonzero()[:5].tolist()
+
+
 # ------------------------------------------------------------------ sub-pixel refinement (build-defined)
 SUBPIXEL_TOL = 1e-3   # px, the tolerance required of sub-pixel disparities; the results are in fact identical
 
