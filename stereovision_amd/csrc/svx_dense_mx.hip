@@ -671,9 +671,92 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     mx_last_output<T, BOTH, EDGE>(acc, st, lane, tid, pass_flags);
 }
 
+// A wavefront behind the frame's last x-block has no pairs of its own.  It takes its share of the workgroup's staging and of
+// writing out the key rows and meets the others once per row, in the same order as mx_strip: a barrier behind the first staged
+// row, one per census row (behind its staging for the next row, which is complete by then: __syncthreads waits for it), and with
+// BOTH one more in front of the last key row.  No matrix instruction, no winner selection.
+template <int T, int WORDS, bool BOTH>
+__device__ __forceinline__ void mx_strip_idle(uint4 *lds, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int cols, int d_base,
+                                              int xl0_wg, int y_lo, int n_rows, int tid, float *__restrict__ part_row, long part_stride) {
+    using G = MxGeom<T, WORDS>;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row_words = (long)cols * WORDS;
+    const uint32_t *const cl0 = cl + (long)(y_lo - 2) * row_words, *const cr0 = cr + (long)(y_lo - 2) * row_words;
+    const uint32_t row_bytes = 4u * (uint32_t)row_words;
+    const __amdgpu_buffer_rsrc_t img_left = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cl0), 0, (int)(row_bytes * (uint32_t)n_rows), 0x00020000);
+    const __amdgpu_buffer_rsrc_t img_right = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cr0), 0, (int)(row_bytes * (uint32_t)n_rows), 0x00020000);
+    auto right_off = [&](int q) -> uint32_t { return 4u * (uint32_t)min(max((long)(xl0_wg - 32 * (T - 1) - d_base - 2) * WORDS + q, 0L), row_words - 1); };
+    auto left_off = [&](int q) -> uint32_t { return 4u * (uint32_t)min(max((long)(xl0_wg - 2) * WORDS + q, 0L), row_words - 1); };
+    auto slot_of = [&](int q, bool left) -> int { return WORDS == 2 ? (q & 1) * G::PLANE + (left ? G::RPX : 0) + (q >> 1) : (left ? G::RPX : 0) + q; };
+    // this thread's word of every staging round (MxGeom): where it comes from, where it goes, whether there is one
+    uint32_t voff[G::ROUNDS], wn[G::ROUNDS], wo[G::ROUNDS];
+    int slot[G::ROUNDS];
+    bool has[G::ROUNDS], left[G::ROUNDS];
+#pragma unroll
+    for (int i = 0; i < G::ROUNDS; ++i) {
+        int q;
+        if (i < G::FR) { q = i * G::NT + tid; left[i] = false; has[i] = true; }
+        else if (i < G::FR + G::FL) { q = (i - G::FR) * G::NT + tid; left[i] = true; has[i] = true; }
+        else {
+            const int v = (i - G::FR - G::FL) * MX_W + wave;
+            left[i] = v < G::ULT;
+            q = left[i] ? G::FL * G::NT + 64 * v + lane : G::FR * G::NT + 64 * (v - G::ULT) + lane;
+            has[i] = v < G::ULT + G::URT && q < (left[i] ? G::LW : G::RW);
+            q = min(q, (left[i] ? G::LW : G::RW) - 1);
+        }
+        voff[i] = left[i] ? left_off(q) : right_off(q);
+        slot[i] = slot_of(q, left[i]);
+    }
+    auto word = [&](int i, int r) -> uint32_t { return left[i] ? mx_word(img_left, (uint32_t)r * row_bytes, voff[i]) : mx_word(img_right, (uint32_t)r * row_bytes, voff[i]); };
+    float *const keys = reinterpret_cast<float *>(lds + MX_NBUF * 2 * G::SLOTS);
+    if (BOTH)
+        for (int i = tid; i < MX_KROWS * G::NKEYS; i += G::NT) keys[i] = MX_NO_KEY;
+    auto flush = [&](int kr) {                       // this thread's keys of key row kr (mx_keys_flush_read / _write)
+#pragma unroll
+        for (int i = 0; i < G::KEY_ROUNDS; ++i)
+            if (tid + i * G::NT < G::NKEYS) {
+                part_row[tid + i * G::NT] = keys[kr * G::NKEYS + tid + i * G::NT];
+                keys[kr * G::NKEYS + tid + i * G::NT] = MX_NO_KEY;
+            }
+        part_row += part_stride;
+    };
+    uint32_t c22;
+    asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
+#pragma unroll
+    for (int i = 0; i < G::ROUNDS; ++i) {
+        if (has[i]) lds[slot[i]] = mx_expand(word(i, 0), c22);
+        wn[i] = word(i, 1);
+        wo[i] = 0u;
+    }
+    __syncthreads();
+    const int last = n_rows - 1;
+    int b_nxt = 1;
+#pragma unroll 1
+    for (int r = 0; r < n_rows; ++r) {
+        uint4 *const img_e = lds + (2 * b_nxt) * G::SLOTS, *const img_l = lds + (2 * b_nxt + 1) * G::SLOTS;
+        const int rn = min(r + 2, last), ro = max(r - 3, 0);
+#pragma unroll
+        for (int i = 0; i < G::ROUNDS; ++i) {
+            if (has[i]) {
+                img_e[slot[i]] = mx_expand(wn[i], c22);
+                img_l[slot[i]] = mx_expand(left[i] ? ~wo[i] : wo[i], c22);       // the leaving row's left words are complemented
+            }
+            wn[i] = word(i, rn);
+            wo[i] = word(i, ro);
+        }
+        __syncthreads();                             // the meeting point of row r
+        if (BOTH && r >= 5) flush(b_nxt);            // the keys of the output row that ended with census row r - 1 (key row (r + 1) % 3)
+        b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
+    }
+    if (BOTH) {
+        __syncthreads();                             // the last output row's keys are complete
+        flush((n_rows - 5) % MX_KROWS);
+    }
+}
+
 // grid: (groups of MX_W x-blocks, strips, frames), MX_W wavefronts per block, one per x-block.  x-block b owns output
 // columns [xl0, xl0 + 32), xl0 = min(2 + 32 b, cols - 34) (the last block is shifted left to end at column cols-3);
-// a wavefront behind the last x-block repeats it (same results to the same places).
+// a wavefront behind the last x-block only helps with the staging (mx_strip_idle).
 // Searches disparities d_base .. min(max_disp, d_base + 32 (T - 1)) - 1; a wider range takes several launches (pass_flags:
 // mx_reduce_tail).  Requires cols >= 36, rows >= 5.
 // BOTH: also stores, for every output row and workgroup, the right view's best key of each of the 32 (MX_W + T - 1) right
@@ -706,7 +789,8 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)gx * G::NKEYS : nullptr;
     // blocks in which the two views admit different pairs
     const bool edge = BOTH && (xl0 - 32 * (T - 1) - d_base < 5 || xl0 + MX_M - 1 > cols - 6);
-    if (edge) mx_strip<T, WORDS, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    if (bx_wave > n_xblocks - 1) mx_strip_idle<T, WORDS, BOTH>(lds, cl, cr, cols, d_base, xl0_wg, y_lo, n_rows, tid, part_row0, part_stride);
+    else if (edge) mx_strip<T, WORDS, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
     else mx_strip<T, WORDS, BOTH, false>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
 
     if (write_border) {
