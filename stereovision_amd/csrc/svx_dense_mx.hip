@@ -137,8 +137,8 @@ constexpr int mx_meet_step() { return PER * (T - 1); }
 // issued: spread over the instructions before the meeting, early enough that the operand wait of the instruction the
 // workgroup meets behind covers the unit's LDS write (LDS operations of a wavefront complete in order, and that
 // instruction's operand was fetched MX_P instructions ahead).
-template <int T, int WORDS, int PER>
-constexpr int mx_unit_step(int v) { return 1 + v * (mx_meet_step<T, PER>() - MX_P - 1) / (2 * MxGeom<T, WORDS>::ROUNDS); }
+template <int T, int TG, int WORDS, int PER>
+constexpr int mx_unit_step(int v) { return 1 + v * (mx_meet_step<T, PER>() - MX_P - 1) / (2 * MxGeom<TG, WORDS>::ROUNDS); }
 
 // Where the operands of a row are: two-word descriptors read the entering and the leaving image at this lane's pixel;
 // with one-word descriptors each of the five instructions of a tile has a read position of its own (cur[j], nxt[j]).
@@ -153,9 +153,11 @@ template <int WORDS> struct MxPtrs;
 template <> struct MxPtrs<2> { const uint4 *cur_e, *cur_l, *nxt_e; };
 template <> struct MxPtrs<1> { const uint4 *cur[5], *nxt[5]; };
 
-template <int T>
+// T: tiles this wavefront computes; TG: tiles of the workgroup's geometry (staged pixels, key rows), T <= TG: an x-block at
+// the frame's left border whose first tiles hold no admissible pair computes the last T of the TG tiles only (mx_strip).
+template <int T, int TG = T>
 struct MxState {
-    using G = MxGeom<T, 2>;                                  // (sized for two-word descriptors; one-word ones use fewer rounds)
+    using G = MxGeom<TG, 2>;                                  // (sized for two-word descriptors; one-word ones use fewer rounds)
     uint32_t wn[G::ROUNDS], wo[G::ROUNDS];                   // census words of the next row to stage (entering, leaving)
     uint32_t voff[G::ROUNDS];                                // byte offset of this thread's word of staging round i in a census row
     int slot0;                                               // where this thread's word of a full round goes in a staged row (+ a constant per round)
@@ -185,22 +187,22 @@ __device__ __forceinline__ void mx_meet() {
 }
 
 // Accumulator element i of tile u as the left view (L) or the right view sees it.
-template <int T, bool EDGE>
-__device__ __forceinline__ float mx_elem_l(const mx_v16f (&acc)[T], const MxState<T> &st, int u, int i) { return EDGE ? acc[u][i] + st.pen_l[u] : acc[u][i]; }
-template <int T, bool EDGE>
+template <int T, bool EDGE, int TG>
+__device__ __forceinline__ float mx_elem_l(const mx_v16f (&acc)[T], const MxState<T, TG> &st, int u, int i) { return EDGE ? acc[u][i] + st.pen_l[u] : acc[u][i]; }
+template <int T, bool EDGE, int TG>
 // (only the last three left columns of an x-block can lie beyond cols - 6: registers 13..15 of the upper lane half)
-__device__ __forceinline__ float mx_elem_r(const mx_v16f (&acc)[T], const MxState<T> &st, int u, int i) { return EDGE && i >= 13 ? acc[u][i] + st.pen_r[i] : acc[u][i]; }
+__device__ __forceinline__ float mx_elem_r(const mx_v16f (&acc)[T], const MxState<T, TG> &st, int u, int i) { return EDGE && i >= 13 ? acc[u][i] + st.pen_r[i] : acc[u][i]; }
 
 // Right view, tile u: the best key of each right column over the tile's 32 left columns, in three pieces.
-template <int T, bool EDGE, int U>
-__device__ __forceinline__ void mx_right_a(const mx_v16f (&acc)[T], const MxState<T> &st, float (&x)[5]) {
+template <int T, bool EDGE, int U, int TG>
+__device__ __forceinline__ void mx_right_a(const mx_v16f (&acc)[T], const MxState<T, TG> &st, float (&x)[5]) {
     x[0] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 0), mx_elem_r<T, EDGE>(acc, st, U, 1), mx_elem_r<T, EDGE>(acc, st, U, 2));
     x[1] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 3), mx_elem_r<T, EDGE>(acc, st, U, 4), mx_elem_r<T, EDGE>(acc, st, U, 5));
     x[2] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 6), mx_elem_r<T, EDGE>(acc, st, U, 7), mx_elem_r<T, EDGE>(acc, st, U, 8));
     x[3] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 9), mx_elem_r<T, EDGE>(acc, st, U, 10), mx_elem_r<T, EDGE>(acc, st, U, 11));
 }
-template <int T, bool EDGE, int U>
-__device__ __forceinline__ void mx_right_b(const mx_v16f (&acc)[T], const MxState<T> &st, float (&x)[5]) {
+template <int T, bool EDGE, int U, int TG>
+__device__ __forceinline__ void mx_right_b(const mx_v16f (&acc)[T], const MxState<T, TG> &st, float (&x)[5]) {
     x[4] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 12), mx_elem_r<T, EDGE>(acc, st, U, 13), mx_elem_r<T, EDGE>(acc, st, U, 14));
     x[0] = mx_max3(x[0], x[1], x[2]);
     x[0] = mx_max3(x[0], x[3], x[4]);
@@ -209,31 +211,31 @@ __device__ __forceinline__ void mx_right_b(const mx_v16f (&acc)[T], const MxStat
 // Both lane halves hold left columns of the same right column; the workgroup's other x-blocks cover it as well: all of
 // them meet in the key row (a 4-byte LDS operation serves the two halves in different cycles, so equal addresses do not collide).
 // KROW: the key row when the caller knows it at compile time (the address is then a constant offset), -1: the one st.kcur points to.
-template <int T, int U, int KROW = -1>
-__device__ __forceinline__ void mx_right_c(MxState<T> &st, const float (&x)[5]) {
-    float *const p = KROW < 0 ? st.kcur + U * 32 : st.key0 + KROW * MxState<T>::G::NKEYS + U * 32;
+template <int T, int U, int KROW = -1, int TG = T>
+__device__ __forceinline__ void mx_right_c(MxState<T, TG> &st, const float (&x)[5]) {
+    float *const p = KROW < 0 ? st.kcur + U * 32 : st.key0 + KROW * MxState<T, TG>::G::NKEYS + U * 32;
     __hip_atomic_fetch_max(p, x[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // The next output row's keys go to the next key row.
-template <int T>
-__device__ __forceinline__ void mx_keys_next_row(MxState<T> &st) {
+template <int T, int TG>
+__device__ __forceinline__ void mx_keys_next_row(MxState<T, TG> &st) {
     st.krow = st.krow == MX_KROWS - 1 ? 0 : st.krow + 1;
-    st.kcur = st.key0 + st.krow * MxState<T>::G::NKEYS;
+    st.kcur = st.key0 + st.krow * MxState<T, TG>::G::NKEYS;
 }
 // Writing out a finished key row, in two pieces (LDS read; store and reset).  The keys of output row r are complete when
 // every wavefront has passed the meeting point of the census row after it (its last tile is read during that row's first
 // products): the row is written out behind that point, while the wavefronts fill the row after it and, those that are ahead,
 // the one after that, which is why three key rows are in use.  Key row `which` (0: the one being filled, MX_KROWS - 1: the one before it).
-template <int T, int KROW = -1>
-__device__ __forceinline__ void mx_keys_flush_read(MxState<T> &st, int which) {
-    using G = typename MxState<T>::G;
+template <int T, int KROW = -1, int TG = T>
+__device__ __forceinline__ void mx_keys_flush_read(MxState<T, TG> &st, int which) {
+    using G = typename MxState<T, TG>::G;
     const int kr = KROW >= 0 ? KROW : st.krow + which >= MX_KROWS ? st.krow + which - MX_KROWS : st.krow + which;
 #pragma unroll
     for (int i = 0; i < G::KEY_ROUNDS; ++i) st.kv[i] = st.kflush0[kr * G::NKEYS + i * 64 * MX_W];   // (a thread without a key in the last round reads inside the LDS block)
 }
-template <int T, int KROW = -1>
-__device__ __forceinline__ void mx_keys_flush_write(MxState<T> &st, int which, int tid) {
-    using G = typename MxState<T>::G;
+template <int T, int KROW = -1, int TG = T>
+__device__ __forceinline__ void mx_keys_flush_write(MxState<T, TG> &st, int which, int tid) {
+    using G = typename MxState<T, TG>::G;
     const int kr = KROW >= 0 ? KROW : st.krow + which >= MX_KROWS ? st.krow + which - MX_KROWS : st.krow + which;
 #pragma unroll
     for (int i = 0; i < G::KEY_ROUNDS; ++i)
@@ -253,8 +255,8 @@ __device__ __forceinline__ float mx_decode(float z) {
 // pass_flags: what a search over part of the disparity range does with the left map.  Bit 0: an earlier pass over smaller
 // disparities left its winner's key in the map, which competes (keys carry their disparity: the larger key is the better
 // pair, the smaller disparity among equal costs); bit 1: a later pass follows, so the key itself is stored, not decoded.
-template <int T>
-__device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane, int pass_flags) {
+template <int T, int TG>
+__device__ __forceinline__ void mx_reduce_tail(MxState<T, TG> &st, int lane, int pass_flags) {
     const float w0 = (lane & 1) ? st.rc[1] : st.rc[0];
     const float w1 = (lane & 1) ? st.rc[3] : st.rc[2];
     float x0, x1;
@@ -289,11 +291,12 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T> &st, int lane, int pas
 // ten window pixels of the entering and the leaving row make five instructions, (e0,e1) (e2,e3) (e4,l0) (l1,l2) (l3,l4),
 // each with its own per-lane read position.  Before the steady state the leaving pixels are not there yet: the fourth
 // and fifth instruction are skipped and the third multiplies its second half by zero.
-template <int T, int WORDS, bool STEADY, bool BOTH, bool EDGE, int KR = -1>
-__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &ptr, uint4 *stage_e, uint4 *stage_l, MxState<T> &st,
+template <int T, int WORDS, bool STEADY, bool BOTH, bool EDGE, int KR = -1, int TG = T>
+__device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &ptr, uint4 *stage_e, uint4 *stage_l, MxState<T, TG> &st,
                                        mx_v8i (&an)[5], uint4 (&fb)[MX_P], const MxRows &rows_g, int lane, int tid, int pass_flags) {
-    using G = MxGeom<T, WORDS>;
+    using G = MxGeom<TG, WORDS>;
     constexpr int PER = WORDS == 2 && STEADY ? 10 : 5, S = T * PER, P = MX_P;
+    constexpr int TILE0 = 32 * (TG - T);             // the first computed tile in the staged right pixels
     constexpr int MEET = mx_meet_step<T, PER>();
     static_assert(S % P == 0 && S - P >= MEET && MEET - P - 1 >= 1, "operands of the next row are fetched behind the meeting point only, into the slots the row expects");
     static_assert(T >= 3, "the fold schedule needs three tiles");
@@ -313,8 +316,8 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
     auto right = [&](int s) -> uint4 {               // right operand of matrix instruction s; s >= S: of the next row's instruction s - S
         const bool next = s >= S;
         const int s2 = next ? s - S : s, t = s2 / PER, j = s2 % PER, k = j % 5;
-        if constexpr (WORDS == 2) return (next ? ptr.nxt_e : j >= 5 ? ptr.cur_l : ptr.cur_e)[32 * t + k];
-        else return (next ? ptr.nxt[j] : ptr.cur[j])[32 * t];
+        if constexpr (WORDS == 2) return (next ? ptr.nxt_e : j >= 5 ? ptr.cur_l : ptr.cur_e)[TILE0 + 32 * t + k];
+        else return (next ? ptr.nxt[j] : ptr.cur[j])[TILE0 + 32 * t];
     };
     float rx[5];
     __builtin_amdgcn_sched_barrier(0);
@@ -337,7 +340,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
         // this thread's share of the next staged rows
         mx_static_for(std::make_integer_sequence<int, 2 * G::ROUNDS>{}, [&](auto v_c) __attribute__((always_inline)) {
             constexpr int v = decltype(v_c)::value;
-            if constexpr (mx_unit_step<T, WORDS, PER>(v) == s && !(MX_X & 1)) {
+            if constexpr (mx_unit_step<T, TG, WORDS, PER>(v) == s && !(MX_X & 1)) {
                 constexpr bool old = v >= G::ROUNDS;                  // entering row first, then the leaving row
                 constexpr int i = old ? v - G::ROUNDS : v;
                 constexpr int kind = i < G::FR ? 0 : i < G::FR + G::FL ? 1 : 2;     // right words, left words, left-over words
@@ -432,8 +435,8 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
 }
 
 // Between the first five rows and the steady state: the first output row's tiles 0 .. T-2.
-template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState<T> &st) {
+template <int T, bool BOTH, bool EDGE, int TG>
+__device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState<T, TG> &st) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         float b = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
@@ -453,8 +456,8 @@ __device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState
 }
 
 // After the last row of a strip: its last tile, the lane reduction and the stores (nothing follows to hide them behind).
-template <int T, bool BOTH, bool EDGE>
-__device__ __forceinline__ void mx_last_output(mx_v16f (&acc)[T], MxState<T> &st, int lane, int tid, int pass_flags) {
+template <int T, bool BOTH, bool EDGE, int TG>
+__device__ __forceinline__ void mx_last_output(mx_v16f (&acc)[T], MxState<T, TG> &st, int lane, int tid, int pass_flags) {
     MX_MATRIX_RESULT_GAP(acc[T - 1]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -486,14 +489,17 @@ __device__ __forceinline__ void mx_last_output(mx_v16f (&acc)[T], MxState<T> &st
 // writes image (r + 1) % 3; a wavefront that is ahead of the others has passed the meeting point of row r - 1 at
 // least, so every wavefront has finished reading the image it overwrites (last read by row r - 2), and what it reads
 // behind the meeting point of row r (the next image) is complete.
-template <int T, int WORDS, bool BOTH, bool EDGE>
+//
+// TG > T: the x-block computes the last T of the geometry's TG tiles only (the others hold no admissible pair: their right
+// columns lie left of the frame).  Staging, key rows and the searched disparity range stay those of TG tiles.
+template <int T, int WORDS, bool BOTH, bool EDGE, int TG = T>
 __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
                                          int cols, int max_disp, int d_base, int pass_flags, int xl0, int xl0_wg, int own_from, int y_lo, int n_rows, int tid,
                                          float *__restrict__ disp, float *__restrict__ part_row0, long part_stride) {
-    using G = MxGeom<T, WORDS>;
+    using G = MxGeom<TG, WORDS>;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
-    const int r0 = xl0 - 32 * (T - 1) - d_base;      // right column of tile 0, lane 0 (this pass searches disparities d_base .. d_base + 32 (T - 1) - 1)
+    const int r0 = xl0 - 32 * (T - 1) - d_base;      // right column of (computed) tile 0, lane 0 (this pass searches disparities d_base .. d_base + 32 (TG - 1) - 1)
 
     // Accumulator element i of tile t is (left column xl0 + m, right column r0 + 32 t + n).  It starts at
     // (1023 - d) / 1024, so that the running window score carries its disparity tag below the integer part
@@ -501,7 +507,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     // right view: right column >= 2 and left column <= cols-6 (the mirror image of the left view's rule); where the
     // two differ (EDGE blocks) the accumulators admit both and each view adds its own penalty when it reads them.
     mx_v16f acc[T];
-    MxState<T> st;
+    MxState<T, TG> st;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int xr = r0 + 32 * t + n;
@@ -510,7 +516,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         for (int i = 0; i < 16; ++i) {
             const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
             const int d = xl0 + m - xr;
-            const bool ok = d >= d_base && d < min(max_disp, d_base + 32 * (T - 1)) && xr >= (BOTH ? 2 : 5);
+            const bool ok = d >= d_base && d < min(max_disp, d_base + 32 * (TG - 1)) && xr >= (BOTH ? 2 : 5);
             acc[t][i] = ok ? (float)(1023 - d) * (1.0f / 1024.0f) : -1048576.0f;
         }
     }
@@ -527,7 +533,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     MxRows rg;
     rg.left = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cl0), 0, (int)(row_bytes * (uint32_t)n_rows), 0x00020000);
     rg.right = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cr0), 0, (int)(row_bytes * (uint32_t)n_rows), 0x00020000);
-    auto right_off = [&](int q) -> uint32_t { return 4u * (uint32_t)min(max((long)(xl0_wg - 32 * (T - 1) - d_base - 2) * WORDS + q, 0L), row_words - 1); };
+    auto right_off = [&](int q) -> uint32_t { return 4u * (uint32_t)min(max((long)(xl0_wg - 32 * (TG - 1) - d_base - 2) * WORDS + q, 0L), row_words - 1); };
     auto left_off = [&](int q) -> uint32_t { return 4u * (uint32_t)min(max((long)(xl0_wg - 2) * WORDS + q, 0L), row_words - 1); };
     auto slot_of = [&](int q, bool left) -> int { return WORDS == 2 ? (q & 1) * G::PLANE + (left ? G::RPX : 0) + (q >> 1) : (left ? G::RPX : 0) + q; };
 #pragma unroll
@@ -566,7 +572,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         // key rows behind the staged images; tile u of this wavefront covers right columns xl0 - 32 (T - 1) - d_base + 32 u + n
         float *const keys = reinterpret_cast<float *>(lds + MX_NBUF * 2 * G::SLOTS);
         for (int i = tid; i < MX_KROWS * G::NKEYS; i += 64 * MX_W) keys[i] = MX_NO_KEY;   // (the meeting behind the first staged row covers this)
-        st.key0 = keys + (xl0 - xl0_wg) + n;
+        st.key0 = keys + (xl0 - xl0_wg) + 32 * (TG - T) + n;
         st.kcur = st.key0;
         st.krow = 0;
         st.kflush0 = keys + tid;
@@ -615,8 +621,8 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     static_assert(MX_P == 5, "the first operands of a row are those of its first tile's five products");
 #pragma unroll
     for (int k = 0; k < 5; ++k) {                    // tile 0: left operands and the first MX_P right operands
-        if constexpr (WORDS == 2) { an[k] = mx_frag(ptr.cur_e[G::RPX + k]); fb[k] = ptr.cur_e[k]; }
-        else { an[k] = mx_frag(ptr.cur[k][G::RPX]); fb[k] = ptr.cur[k][0]; }
+        if constexpr (WORDS == 2) { an[k] = mx_frag(ptr.cur_e[G::RPX + k]); fb[k] = ptr.cur_e[32 * (TG - T) + k]; }
+        else { an[k] = mx_frag(ptr.cur[k][G::RPX]); fb[k] = ptr.cur[k][32 * (TG - T)]; }
     }
 
     // row r stages row r+1 (entering) with row r-4 (leaving) and fetches the words of rows r+2 and r-3
@@ -789,8 +795,17 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)gx * G::NKEYS : nullptr;
     // blocks in which the two views admit different pairs
     const bool edge = BOTH && (xl0 - 32 * (T - 1) - d_base < 5 || xl0 + MX_M - 1 > cols - 6);
+    // x-blocks at the frame's left border (and, in a later pass, left of its first disparity): tile u holds right columns
+    // xl0 - 32 (T - 1) - d_base + 32 u .. + 31, and the first tiles, whose columns all lie left of column 2, hold no admissible pair.
+    // With five tiles up to two of them are not computed (three is the fewest the row's timetable takes).
+    int dead = 0;
+    if constexpr (T == 5) dead = min(max((32 * (T - 1) - 29 + d_base - xl0 + 31) / 32, 0), 2);
     if (bx_wave > n_xblocks - 1) mx_strip_idle<T, WORDS, BOTH>(lds, cl, cr, cols, d_base, xl0_wg, y_lo, n_rows, tid, part_row0, part_stride);
-    else if (edge) mx_strip<T, WORDS, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    else if (T == 5 && dead == 2) {
+        if constexpr (T == 5) mx_strip<3, WORDS, BOTH, BOTH, 5>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    } else if (T == 5 && dead == 1) {
+        if constexpr (T == 5) mx_strip<4, WORDS, BOTH, BOTH, 5>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    } else if (edge) mx_strip<T, WORDS, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
     else mx_strip<T, WORDS, BOTH, false>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
 
     if (write_border) {
