@@ -356,7 +356,16 @@ def main():
             # two-word descriptors: ten products per tile and row (five while a strip's first five rows fill the window); one-word
             # descriptors put two window pixels in one product: five per tile and row (three while the window fills)
             per_tile = (10 * (rows - 4 + 4 * strips) - 25 * strips) if words == 2 else (5 * (rows - 4 + 4 * strips) - 10 * strips)
-            mfma_count = passes * tiles * per_tile * ((cols - 4 + 31) // 32) * F
+            # tiles a row of x-blocks computes: an x-block at the frame's left border (or, in a later pass, left of the pass's first
+            # disparity) leaves out up to two of five tiles whose right columns all lie left of column 2
+            n_blocks = (cols - 4 + 31) // 32
+            tile_units = 0
+            for p_ in range(passes):
+                for b in range(n_blocks):
+                    xl0 = min(2 + 32 * b, cols - 34)
+                    dead = min(max(-(-(32 * (tiles - 1) - 29 + 128 * p_ - xl0) // 32), 0), 2) if tiles == 5 else 0
+                    tile_units += tiles - dead
+            mfma_count = tile_units * per_tile * F
             issued_flops = 2.0 * 32 * 32 * 64 * mfma_count
             alg_flops = 2.0 * 2 * 5 * 32 * words * pixdisp_per_frame * F
             # The headline stays the vector-popcount floor (one xor + one popcount per descriptor word and pix*disp), the
