@@ -287,6 +287,44 @@ def test_matrix_search_strip_lengths(ctx, strip_rows, D, words):
     assert torch.equal(mr, wr), (mr != wr).nonzero()[:5].tolist()
 
 
+@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+def test_matrix_search_random_sizes(ctx, seed):
+    """Fifteen random sizes per seed (widths that leave idle wavefronts or a shifted last x-block, forced short strips, every
+    tile count, both descriptor widths, one to three frames): left view, both views and the fused left-right entry against
+    the vector sweep."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    rng = np.random.default_rng(seed)
+    for case in range(15):
+        cols = int(rng.choice([rng.integers(36, 80), rng.integers(80, 400), rng.integers(400, 1400)]))
+        rows = int(rng.integers(5, 90))
+        D = int(rng.choice([rng.integers(1, 65), rng.integers(65, 129), rng.integers(129, 400)]))
+        words = int(rng.integers(1, 3))
+        frames = int(rng.integers(1, 4))
+        strip = int(rng.choice([0, 0, rng.integers(1, 12)]))
+        what = "rows=%d cols=%d D=%d words=%d frames=%d strip=%d" % (rows, cols, D, words, frames, strip)
+        ls, rs = synth.stereo_batch(rows, cols, min(D, max(cols // 2, 1)), frames, seed0=100 * seed + case)
+        dl, dr = dev(ls), dev(rs)
+        cl, cr = (ctx.census9x7(dl), ctx.census9x7(dr)) if words == 2 else (ctx.census5x5(dl), ctx.census5x5(dr))
+        ctx.set_option(S.OPT_MATRIX_CORES, 0)
+        try:
+            wl = ctx.dense_wta(cl, cr, D, S.VIEW_LEFT, words)
+            wr = ctx.dense_wta(cl, cr, D, S.VIEW_RIGHT, words)
+        finally:
+            ctx.set_option(S.OPT_MATRIX_CORES, -1)
+        ctx.set_option(S.OPT_MX_STRIP_ROWS, strip)
+        try:
+            ml, mr = ctx.dense_wta_both(cl, cr, D, words)
+            ml0 = ctx.dense_wta(cl, cr, D, S.VIEW_LEFT, words)
+            fused = ctx.dense_census9x7_lr(dl, dr, D, lr_threshold=1.0) if words == 2 else None
+        finally:
+            ctx.set_option(S.OPT_MX_STRIP_ROWS, 0)
+        assert torch.equal(ml, wl) and torch.equal(ml0, wl), what
+        assert torch.equal(mr, wr), what
+        if fused is not None:
+            assert torch.equal(fused, ctx.lr_check(wl.clone(), wr, 1.0)), what
+
+
 # ------------------------------------------------------------------ sub-pixel refinement (build-defined)
 SUBPIXEL_TOL = 1e-3   # px, the tolerance required of sub-pixel disparities; the results are in fact identical
 
