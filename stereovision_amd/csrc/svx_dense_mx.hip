@@ -165,7 +165,7 @@ struct MxState {
     bool t_any[2], t_left[2], t_has[2];                      // those rounds: this wavefront takes part / stages left words / this lane holds a word
     bool own;                                                // this lane's left column belongs to this x-block alone (the last block is shifted over its neighbour)
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
-    float pen_l[T], pen_r[16];                               // border blocks: what each view must not use (0 or -2^21)
+    float lift_r[T], lift_l;                                 // both views: what the right view adds to a tile's best key and the left view to its winner (0 or 4096, see mx_strip)
     float *out_row;                                          // left map: the x-block's first pixel of the row being written (the same for every lane) ...
     uint32_t out_off;                                        // ... and this lane's byte offset from it
     long out_stride;
@@ -186,27 +186,28 @@ __device__ __forceinline__ void mx_meet() {
     if (!(MX_X & 4)) asm volatile("s_barrier" ::: "memory");
 }
 
-// Accumulator element i of tile u as the left view (L) or the right view sees it.
-template <int T, bool EDGE, int TG>
-__device__ __forceinline__ float mx_elem_l(const mx_v16f (&acc)[T], const MxState<T, TG> &st, int u, int i) { return EDGE ? acc[u][i] + st.pen_l[u] : acc[u][i]; }
-template <int T, bool EDGE, int TG>
-// (only the last three left columns of an x-block can lie beyond cols - 6: registers 13..15 of the upper lane half)
-__device__ __forceinline__ float mx_elem_r(const mx_v16f (&acc)[T], const MxState<T, TG> &st, int u, int i) { return EDGE && i >= 13 ? acc[u][i] + st.pen_r[i] : acc[u][i]; }
+// Accumulator element i of tile u as the left view (L) or the right view reads it: as it is (what a view must not use was
+// lowered when the accumulators were started, mx_strip).
+template <int T, int TG>
+__device__ __forceinline__ float mx_elem_l(const mx_v16f (&acc)[T], const MxState<T, TG> &st, int u, int i) { return acc[u][i]; }
+template <int T, int TG>
+__device__ __forceinline__ float mx_elem_r(const mx_v16f (&acc)[T], const MxState<T, TG> &st, int u, int i) { return acc[u][i]; }
 
 // Right view, tile u: the best key of each right column over the tile's 32 left columns, in three pieces.
-template <int T, bool EDGE, int U, int TG>
+template <int T, int U, int TG>
 __device__ __forceinline__ void mx_right_a(const mx_v16f (&acc)[T], const MxState<T, TG> &st, float (&x)[5]) {
-    x[0] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 0), mx_elem_r<T, EDGE>(acc, st, U, 1), mx_elem_r<T, EDGE>(acc, st, U, 2));
-    x[1] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 3), mx_elem_r<T, EDGE>(acc, st, U, 4), mx_elem_r<T, EDGE>(acc, st, U, 5));
-    x[2] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 6), mx_elem_r<T, EDGE>(acc, st, U, 7), mx_elem_r<T, EDGE>(acc, st, U, 8));
-    x[3] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 9), mx_elem_r<T, EDGE>(acc, st, U, 10), mx_elem_r<T, EDGE>(acc, st, U, 11));
+    x[0] = mx_max3(mx_elem_r<T>(acc, st, U, 0), mx_elem_r<T>(acc, st, U, 1), mx_elem_r<T>(acc, st, U, 2));
+    x[1] = mx_max3(mx_elem_r<T>(acc, st, U, 3), mx_elem_r<T>(acc, st, U, 4), mx_elem_r<T>(acc, st, U, 5));
+    x[2] = mx_max3(mx_elem_r<T>(acc, st, U, 6), mx_elem_r<T>(acc, st, U, 7), mx_elem_r<T>(acc, st, U, 8));
+    x[3] = mx_max3(mx_elem_r<T>(acc, st, U, 9), mx_elem_r<T>(acc, st, U, 10), mx_elem_r<T>(acc, st, U, 11));
 }
-template <int T, bool EDGE, int U, int TG>
+template <int T, int U, int TG>
 __device__ __forceinline__ void mx_right_b(const mx_v16f (&acc)[T], const MxState<T, TG> &st, float (&x)[5]) {
-    x[4] = mx_max3(mx_elem_r<T, EDGE>(acc, st, U, 12), mx_elem_r<T, EDGE>(acc, st, U, 13), mx_elem_r<T, EDGE>(acc, st, U, 14));
+    x[4] = mx_max3(mx_elem_r<T>(acc, st, U, 12), mx_elem_r<T>(acc, st, U, 13), mx_elem_r<T>(acc, st, U, 14));
     x[0] = mx_max3(x[0], x[1], x[2]);
     x[0] = mx_max3(x[0], x[3], x[4]);
-    x[0] = mx_max(x[0], mx_elem_r<T, EDGE>(acc, st, U, 15));
+    x[0] = mx_max(x[0], mx_elem_r<T>(acc, st, U, 15));
+    x[0] += st.lift_r[U];                                    // right columns 2..4: every pair of theirs starts 4096 lower (mx_strip)
 }
 // Both lane halves hold left columns of the same right column; the workgroup's other x-blocks cover it as well: all of
 // them meet in the key row (a 4-byte LDS operation serves the two halves in different cycles, so equal addresses do not collide).
@@ -246,16 +247,17 @@ __device__ __forceinline__ void mx_keys_flush_write(MxState<T, TG> &st, int whic
     st.part_row += st.part_stride;
 }
 
-// Decodes the winner of a left pixel: key = window score + (1023 - d) / 1024; an inadmissible pair sits near -2^20.
+// Decodes a winner: key = window score + (1023 - d) / 1024 >= -1600; an inadmissible pair sits near -2^20, and a pair that
+// only the other view admits, unlifted, below -2495 (mx_strip).
 __device__ __forceinline__ float mx_decode(float z) {
     const float frac = z - __builtin_floorf(z);
-    return z < -524288.0f ? 0.0f : 1023.0f - frac * 1024.0f;
+    return z < -2048.0f ? 0.0f : 1023.0f - frac * 1024.0f;
 }
 
 // pass_flags: what a search over part of the disparity range does with the left map.  Bit 0: an earlier pass over smaller
 // disparities left its winner's key in the map, which competes (keys carry their disparity: the larger key is the better
 // pair, the smaller disparity among equal costs); bit 1: a later pass follows, so the key itself is stored, not decoded.
-template <int T, int TG>
+template <int T, bool BOTH, int TG>
 __device__ __forceinline__ void mx_reduce_tail(MxState<T, TG> &st, int lane, int pass_flags) {
     const float w0 = (lane & 1) ? st.rc[1] : st.rc[0];
     const float w1 = (lane & 1) ? st.rc[3] : st.rc[2];
@@ -267,6 +269,7 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T, TG> &st, int lane, int
     float z = (lane & 2) ? x1 : x0;                          // lane l: register (l & 15) over its 16-lane row
     const float zo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, z), 0x401f));   // lane ^ 16
     z = mx_max(z, zo);
+    if (BOTH) z += st.lift_l;                                // left columns cols-5..cols-3: every pair of theirs starts 4096 lower (mx_strip)
     if (st.own) {                                            // (a column that two x-blocks cover is written by one of them: with passes the map is read back)
         float *const out = reinterpret_cast<float *>(reinterpret_cast<char *>(st.out_row) + st.out_off);
         if (pass_flags & 1) z = mx_max(z, *out);
@@ -291,7 +294,7 @@ __device__ __forceinline__ void mx_reduce_tail(MxState<T, TG> &st, int lane, int
 // ten window pixels of the entering and the leaving row make five instructions, (e0,e1) (e2,e3) (e4,l0) (l1,l2) (l3,l4),
 // each with its own per-lane read position.  Before the steady state the leaving pixels are not there yet: the fourth
 // and fifth instruction are skipped and the third multiplies its second half by zero.
-template <int T, int WORDS, bool STEADY, bool BOTH, bool EDGE, int KR = -1, int TG = T>
+template <int T, int WORDS, bool STEADY, bool BOTH, int KR = -1, int TG = T>
 __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &ptr, uint4 *stage_e, uint4 *stage_l, MxState<T, TG> &st,
                                        mx_v8i (&an)[5], uint4 (&fb)[MX_P], const MxRows &rows_g, int lane, int tid, int pass_flags) {
     using G = MxGeom<TG, WORDS>;
@@ -382,38 +385,38 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
             constexpr int e = 2 * (j - 2);                             // slots 2 .. 9 take two accumulator elements each
             if constexpr (T == 5) {
                 if constexpr (t == 0 && j >= 2) {                      // tiles 3 and 4 of the previous row
-                    st.best[e] = mx_max3(st.best[e], mx_elem_l<T, EDGE>(acc, st, 3, e), mx_elem_l<T, EDGE>(acc, st, 4, e));
-                    st.best[e + 1] = mx_max3(st.best[e + 1], mx_elem_l<T, EDGE>(acc, st, 3, e + 1), mx_elem_l<T, EDGE>(acc, st, 4, e + 1));
+                    st.best[e] = mx_max3(st.best[e], mx_elem_l<T>(acc, st, 3, e), mx_elem_l<T>(acc, st, 4, e));
+                    st.best[e + 1] = mx_max3(st.best[e + 1], mx_elem_l<T>(acc, st, 3, e + 1), mx_elem_l<T>(acc, st, 4, e + 1));
                 }
                 if constexpr (t == 3 && j >= 2) {                      // tiles 0, 1 and 2 of this row
-                    st.best[e] = mx_max3(mx_elem_l<T, EDGE>(acc, st, 0, e), mx_elem_l<T, EDGE>(acc, st, 1, e), mx_elem_l<T, EDGE>(acc, st, 2, e));
-                    st.best[e + 1] = mx_max3(mx_elem_l<T, EDGE>(acc, st, 0, e + 1), mx_elem_l<T, EDGE>(acc, st, 1, e + 1), mx_elem_l<T, EDGE>(acc, st, 2, e + 1));
+                    st.best[e] = mx_max3(mx_elem_l<T>(acc, st, 0, e), mx_elem_l<T>(acc, st, 1, e), mx_elem_l<T>(acc, st, 2, e));
+                    st.best[e + 1] = mx_max3(mx_elem_l<T>(acc, st, 0, e + 1), mx_elem_l<T>(acc, st, 1, e + 1), mx_elem_l<T>(acc, st, 2, e + 1));
                 }
             } else {
                 if constexpr (t == 0 && j >= 2) {                      // last tile of the previous row
-                    st.best[e] = mx_max(st.best[e], mx_elem_l<T, EDGE>(acc, st, T - 1, e));
-                    st.best[e + 1] = mx_max(st.best[e + 1], mx_elem_l<T, EDGE>(acc, st, T - 1, e + 1));
+                    st.best[e] = mx_max(st.best[e], mx_elem_l<T>(acc, st, T - 1, e));
+                    st.best[e + 1] = mx_max(st.best[e + 1], mx_elem_l<T>(acc, st, T - 1, e + 1));
                 }
                 if constexpr (t == 2 && j >= 5 && j < 9) {             // tiles 0 and 1 of this row
 #pragma unroll
                     for (int i = 4 * (j - 5); i < 4 * (j - 5) + 4; ++i)
-                        st.best[i] = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
+                        st.best[i] = mx_max(mx_elem_l<T>(acc, st, 0, i), mx_elem_l<T>(acc, st, 1, i));
                 }
                 if constexpr (t >= 3 && j >= 2) {                      // tile t - 1 of this row
-                    st.best[e] = mx_max(st.best[e], mx_elem_l<T, EDGE>(acc, st, t - 1, e));
-                    st.best[e + 1] = mx_max(st.best[e + 1], mx_elem_l<T, EDGE>(acc, st, t - 1, e + 1));
+                    st.best[e] = mx_max(st.best[e], mx_elem_l<T>(acc, st, t - 1, e));
+                    st.best[e + 1] = mx_max(st.best[e + 1], mx_elem_l<T>(acc, st, t - 1, e + 1));
                 }
             }
             if constexpr (t == 1 && j < 8) { MX_RED_A(j); }
             if constexpr (t == 2 && j == 0) { MX_RED_B(0); MX_RED_B(1); }
             if constexpr (t == 2 && j == 1) { MX_RED_B(2); MX_RED_B(3); }
             if constexpr (t == 2 && j == 2) { MX_RED_C(); }
-            if constexpr (t == 2 && j == 3) { mx_reduce_tail<T>(st, lane, pass_flags); st.out_row += st.out_stride; }
+            if constexpr (t == 2 && j == 3) { mx_reduce_tail<T, BOTH>(st, lane, pass_flags); st.out_row += st.out_stride; }
             // right view: tile t - 1 of this row, or the last tile of the previous row
             if constexpr (BOTH) {
                 constexpr int u = t == 0 ? T - 1 : t - 1;
-                if constexpr (j == 4) mx_right_a<T, EDGE, u>(acc, st, rx);
-                if constexpr (j == 8) mx_right_b<T, EDGE, u>(acc, st, rx);
+                if constexpr (j == 4) mx_right_a<T, u>(acc, st, rx);
+                if constexpr (j == 8) mx_right_b<T, u>(acc, st, rx);
                 if constexpr (j == 9) {
                     if constexpr (KR < 0) {
                         mx_right_c<T, u>(st, rx);
@@ -435,34 +438,34 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
 }
 
 // Between the first five rows and the steady state: the first output row's tiles 0 .. T-2.
-template <int T, bool BOTH, bool EDGE, int TG>
+template <int T, bool BOTH, int TG>
 __device__ __forceinline__ void mx_first_output(const mx_v16f (&acc)[T], MxState<T, TG> &st) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        float b = mx_max(mx_elem_l<T, EDGE>(acc, st, 0, i), mx_elem_l<T, EDGE>(acc, st, 1, i));
+        float b = mx_max(mx_elem_l<T>(acc, st, 0, i), mx_elem_l<T>(acc, st, 1, i));
 #pragma unroll
-        for (int u = 2; u < (T == 5 ? 3 : T - 1); ++u) b = mx_max(b, mx_elem_l<T, EDGE>(acc, st, u, i));   // the rest follows with the next row
+        for (int u = 2; u < (T == 5 ? 3 : T - 1); ++u) b = mx_max(b, mx_elem_l<T>(acc, st, u, i));   // the rest follows with the next row
         st.best[i] = b;
     }
     if (BOTH) {
         mx_static_for(std::make_integer_sequence<int, T - 1>{}, [&](auto u_c) __attribute__((always_inline)) {
             constexpr int u = decltype(u_c)::value;
             float rx[5];
-            mx_right_a<T, EDGE, u>(acc, st, rx);
-            mx_right_b<T, EDGE, u>(acc, st, rx);
+            mx_right_a<T, u>(acc, st, rx);
+            mx_right_b<T, u>(acc, st, rx);
             mx_right_c<T, u>(st, rx);
         });
     }
 }
 
 // After the last row of a strip: its last tile, the lane reduction and the stores (nothing follows to hide them behind).
-template <int T, bool BOTH, bool EDGE, int TG>
+template <int T, bool BOTH, int TG>
 __device__ __forceinline__ void mx_last_output(mx_v16f (&acc)[T], MxState<T, TG> &st, int lane, int tid, int pass_flags) {
     MX_MATRIX_RESULT_GAP(acc[T - 1]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        if (T == 5) st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, 3, i));
-        st.best[i] = mx_max(st.best[i], mx_elem_l<T, EDGE>(acc, st, T - 1, i));
+        if (T == 5) st.best[i] = mx_max(st.best[i], mx_elem_l<T>(acc, st, 3, i));
+        st.best[i] = mx_max(st.best[i], mx_elem_l<T>(acc, st, T - 1, i));
     }
     MX_DPP_GAP();
     MX_RED_A(0); MX_RED_A(1); MX_RED_A(2); MX_RED_A(3); MX_RED_A(4); MX_RED_A(5); MX_RED_A(6); MX_RED_A(7);
@@ -470,11 +473,11 @@ __device__ __forceinline__ void mx_last_output(mx_v16f (&acc)[T], MxState<T, TG>
     MX_RED_B(0); MX_RED_B(1); MX_RED_B(2); MX_RED_B(3);
     MX_DPP_GAP();
     MX_RED_C();
-    mx_reduce_tail<T>(st, lane, pass_flags);
+    mx_reduce_tail<T, BOTH>(st, lane, pass_flags);
     if (BOTH) {
         float rx[5];
-        mx_right_a<T, EDGE, T - 1>(acc, st, rx);
-        mx_right_b<T, EDGE, T - 1>(acc, st, rx);
+        mx_right_a<T, T - 1>(acc, st, rx);
+        mx_right_b<T, T - 1>(acc, st, rx);
         mx_right_c<T, T - 1>(st, rx);
         __syncthreads();                                     // the last output row's keys are complete
         mx_keys_flush_read<T>(st, 0);
@@ -492,7 +495,7 @@ __device__ __forceinline__ void mx_last_output(mx_v16f (&acc)[T], MxState<T, TG>
 //
 // TG > T: the x-block computes the last T of the geometry's TG tiles only (the others hold no admissible pair: their right
 // columns lie left of the frame).  Staging, key rows and the searched disparity range stay those of TG tiles.
-template <int T, int WORDS, bool BOTH, bool EDGE, int TG = T>
+template <int T, int WORDS, bool BOTH, int TG = T>
 __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
                                          int cols, int max_disp, int d_base, int pass_flags, int xl0, int xl0_wg, int own_from, int y_lo, int n_rows, int tid,
                                          float *__restrict__ disp, float *__restrict__ part_row0, long part_stride) {
@@ -504,24 +507,29 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     // Accumulator element i of tile t is (left column xl0 + m, right column r0 + 32 t + n).  It starts at
     // (1023 - d) / 1024, so that the running window score carries its disparity tag below the integer part
     // (21 significant bits: exact), or near -2^20 when the pair is inadmissible.  Left view: right column >= 5;
-    // right view: right column >= 2 and left column <= cols-6 (the mirror image of the left view's rule); where the
-    // two differ (EDGE blocks) the accumulators admit both and each view adds its own penalty when it reads them.
+    // right view: right column >= 2 and left column <= cols-6 (the mirror image of the left view's rule).  A pair that
+    // only ONE of the views admits (right columns 2..4; left columns cols-5..cols-3) starts 4096 lower (still exact: 23
+    // significant bits, keys stay above -8192).  The other view never prefers it to a pair of its own (those lie above
+    // -1600) and decodes it as "no disparity" when it has none (mx_decode).  The view that admits it gets the true key
+    // back by adding 4096 AFTER its reduction: such a right column holds nothing but lowered or inadmissible pairs, so the
+    // right view lifts the tile's best key of that lane (lift_r, one addition per tile), and such a left column likewise,
+    // so the left view lifts its winner (lift_l, one addition per row).  No accumulator read pays for the frame's borders.
     mx_v16f acc[T];
     MxState<T, TG> st;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int xr = r0 + 32 * t + n;
-        st.pen_l[t] = xr >= 5 ? 0.0f : -2097152.0f;
+        st.lift_r[t] = BOTH && xr < 5 ? 4096.0f : 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
             const int d = xl0 + m - xr;
-            const bool ok = d >= d_base && d < min(max_disp, d_base + 32 * (TG - 1)) && xr >= (BOTH ? 2 : 5);
-            acc[t][i] = ok ? (float)(1023 - d) * (1.0f / 1024.0f) : -1048576.0f;
+            const bool in_range = d >= d_base && d < min(max_disp, d_base + 32 * (TG - 1));
+            const bool ok_l = xr >= 5, ok_r = xr >= 2 && xl0 + m <= cols - 6;          // what the left / the right view admits
+            const bool ok = in_range && (BOTH ? ok_l || ok_r : ok_l);
+            acc[t][i] = ok ? (float)(1023 - d) * (1.0f / 1024.0f) - (BOTH && !(ok_l && ok_r) ? 4096.0f : 0.0f) : -1048576.0f;
         }
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) st.pen_r[i] = xl0 + (i & 3) + 8 * (i >> 2) + 4 * h <= cols - 6 ? 0.0f : -2097152.0f;
 
     // staging (rounds: MxGeom): right word q of a staged row is word (xl0_wg - 32 (T - 1) - d_base - 2) * WORDS + q of the right
     // census row, left word q is word (xl0_wg - 2) * WORDS + q of the left one.  Words outside the frame are clamped into it:
@@ -567,6 +575,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     st.out_row = disp + (long)y_lo * cols + xl0;
     st.out_off = 4u * (uint32_t)((i_out & 3) + 8 * (i_out >> 2) + 4 * h);
     st.own = xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h >= own_from;
+    st.lift_l = BOTH && xl0 + (i_out & 3) + 8 * (i_out >> 2) + 4 * h > cols - 6 ? 4096.0f : 0.0f;
     st.out_stride = cols;
     if (BOTH) {
         // key rows behind the staged images; tile u of this wavefront covers right columns xl0 - 32 (T - 1) - d_base + 32 u + n
@@ -630,12 +639,12 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     for (int r = 0; r < 5; ++r) {
         rg.off_new = (uint32_t)min(r + 2, last) * row_bytes;
         rg.off_old = (uint32_t)max(r - 3, 0) * row_bytes;
-        mx_row<T, WORDS, false, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, rg, lane, tid, pass_flags);
+        mx_row<T, WORDS, false, BOTH>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, rg, lane, tid, pass_flags);
         b_cur = b_nxt;
         b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
         point(b_cur, b_nxt);
     }
-    mx_first_output<T, BOTH, EDGE>(acc, st);
+    mx_first_output<T, BOTH>(acc, st);
     // Steady state, three rows per trip: census row r reads staged image r % 3 and writes image (r + 1) % 3, and the keys of
     // the output row that ends with it go to key row (r + 1) % 3, so with the phase of a row a compile-time constant every
     // LDS address of the row is a constant offset from a register that never changes.
@@ -645,7 +654,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         rg.off_new = (uint32_t)min(r + 2, last) * row_bytes;
         rg.off_old = (uint32_t)(r - 3) * row_bytes;
         point(B, N);
-        mx_row<T, WORDS, true, BOTH, EDGE, N>(acc, ptr, img_e(N), img_l(N), st, an, fb, rg, lane, tid, pass_flags);
+        mx_row<T, WORDS, true, BOTH, N>(acc, ptr, img_e(N), img_l(N), st, an, fb, rg, lane, tid, pass_flags);
     };
     if constexpr (T <= 5) {
         int r = 5;
@@ -668,13 +677,13 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         for (int r = 5; r < n_rows; ++r) {
             rg.off_new = (uint32_t)min(r + 2, last) * row_bytes;
             rg.off_old = (uint32_t)(r - 3) * row_bytes;
-            mx_row<T, WORDS, true, BOTH, EDGE>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, rg, lane, tid, pass_flags);
+            mx_row<T, WORDS, true, BOTH>(acc, ptr, img_e(b_nxt), img_l(b_nxt), st, an, fb, rg, lane, tid, pass_flags);
             b_cur = b_nxt;
             b_nxt = b_nxt == MX_NBUF - 1 ? 0 : b_nxt + 1;
             point(b_cur, b_nxt);
         }
     }
-    mx_last_output<T, BOTH, EDGE>(acc, st, lane, tid, pass_flags);
+    mx_last_output<T, BOTH>(acc, st, lane, tid, pass_flags);
 }
 
 // A wavefront behind the frame's last x-block has no pairs of its own.  It takes its share of the workgroup's staging and of
@@ -793,8 +802,6 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     const int n_rows = y_hi - y_lo + 4;              // census rows y_lo-2 .. y_hi+1
     const long part_stride = (long)gridDim.x * G::NKEYS;
     float *part_row0 = BOTH ? partial + ((long)bz * rows + y_lo) * part_stride + (long)gx * G::NKEYS : nullptr;
-    // blocks in which the two views admit different pairs
-    const bool edge = BOTH && (xl0 - 32 * (T - 1) - d_base < 5 || xl0 + MX_M - 1 > cols - 6);
     // x-blocks at the frame's left border (and, in a later pass, left of its first disparity): tile u holds right columns
     // xl0 - 32 (T - 1) - d_base + 32 u .. + 31, and the first tiles, whose columns all lie left of column 2, hold no admissible pair.
     // With five tiles up to two of them are not computed (three is the fewest the row's timetable takes).
@@ -802,11 +809,10 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     if constexpr (T == 5) dead = min(max((32 * (T - 1) - 29 + d_base - xl0 + 31) / 32, 0), 2);
     if (bx_wave > n_xblocks - 1) mx_strip_idle<T, WORDS, BOTH>(lds, cl, cr, cols, d_base, xl0_wg, y_lo, n_rows, tid, part_row0, part_stride);
     else if (T == 5 && dead == 2) {
-        if constexpr (T == 5) mx_strip<3, WORDS, BOTH, BOTH, 5>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+        if constexpr (T == 5) mx_strip<3, WORDS, BOTH, 5>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
     } else if (T == 5 && dead == 1) {
-        if constexpr (T == 5) mx_strip<4, WORDS, BOTH, BOTH, 5>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
-    } else if (edge) mx_strip<T, WORDS, BOTH, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
-    else mx_strip<T, WORDS, BOTH, false>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+        if constexpr (T == 5) mx_strip<4, WORDS, BOTH, 5>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
+    } else mx_strip<T, WORDS, BOTH>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
 
     if (write_border) {
         // rows outside [2, rows-2) over this block's columns, and the two border columns on either side
