@@ -14,6 +14,7 @@ on, D = 128, `--frames` frames per GPU (weak scaling: every rank owns its own ba
 in the data path).  Prints ONE JSON line on rank 0.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, one per GPU, see launch_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -21,6 +22,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,7 +44,7 @@ HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec
 VALU_PEAK_TLOPS = 256 * 64 * 2.4e9 / 1e12      # 256 CUs x 64 lanes/clk x 2.4 GHz = 39.3 T lane-instr/s (v_xor / v_bcnt measured at this rate)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # (defaults: the first dozen launches after an idle spell run up to 20 % slower while the clocks settle, so the warm-up
@@ -61,7 +64,32 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend; gloo with --one-device rehearses the multi-rank path on a one-GPU box")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
-    return ap.parse_args()
+    ap.add_argument("--preroll", type=int, default=-1,
+                    help="untimed steps in front of the --warmup steps (default -1: as many as bring the untimed steps to 20, "
+                         "because the first dozen launches after an idle spell run slower; 0: exactly --warmup untimed steps)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: the ranks only rendezvous, time an empty region the same way and rank 0 prints a short line "
+                         "(checks the launcher and the rank plumbing on a host without a GPU)")
+    return ap.parse_args(argv)
+
+
+def launch_command(n, port, argv):
+    """The command that starts n ranks of this script on this node (what the driver's N > 1 form spells out by hand)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` from a bare shell: this process has not touched the GPU (nothing that initialises it has been
+    imported or called yet); it starts the N ranks as a child job, passes their output through (rank 0 prints the JSON
+    line) and returns the job's exit code.  The ranks find WORLD_SIZE set and do not come back here."""
+    with socket.socket() as s:                   # a free port for the rendezvous
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.call(launch_command(n, port, argv), env=env)
 
 
 def cpu_baseline_9x7(left, right, D, n_frames_work, lr, lr_threshold):
@@ -184,16 +212,40 @@ def cpu_baseline(left, right, D, n_frames_work):
     }, out, min(rows - 4, total_rows)
 
 
+def dry_run(args, world, rank):
+    """The rank plumbing without a GPU: rendezvous, the barrier / max-over-ranks bracket around an empty region, one line."""
+    import torch
+    import torch.distributed as dist
+    from stereovision_amd import sharding
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding.barrier()
+    t0 = time.perf_counter()
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+    seeds = sharding.frame_seeds(rank, args.frames)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                          "rank0_first_seed": seeds[0], "elapsed_s": round(elapsed, 6)}))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     import torch
     import torch.distributed as dist
     import stereovision_amd as S
     from stereovision_amd import sharding, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.one_device:
         local_rank = 0
     if world > 1:
@@ -239,7 +291,7 @@ def main():
 
     # The first dozen launches after an idle spell run up to 20 % slower while the clocks settle: when the caller asks for
     # fewer than 20 warm-up steps, untimed steps in front of them make up the difference (reported as "preroll_steps").
-    preroll = max(0, 20 - args.warmup)
+    preroll = max(0, 20 - args.warmup) if args.preroll < 0 else args.preroll
     for _ in range(preroll + args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -308,11 +360,13 @@ def main():
             measured_peak = None
         achieved = valu_ops / (k_ms * 1e-3) / 1e12
         traffic = None   # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        traffic_source = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_w%d%s%s.json" % (words, "_both" if both_views else "",
-                                                                                         "_mx" if on_matrix_cores else ""))))
-            if tj["kernel"] == kernel_name and tj["words"] == words and F == 64 and D == 128:
+            traffic_file = "traffic_w%d%s%s.json" % (words, "_both" if both_views else "", "_mx" if on_matrix_cores else "")
+            tj = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
+            if tj["kernel"] == kernel_name and tj["words"] == words and F == 64 and D == 128 and (rows, cols) == (368, 1232):
                 traffic = (tj.get("fetch_correction", 1.0) * tj["fetch_size_kb"] + tj["write_size_kb"]) * 1024.0
+                traffic_source = "profiles/" + traffic_file + " (rocprofv3 PMC passes of this kernel, not measured in this run)"
         except Exception:
             traffic = None
         roofline = {
@@ -323,6 +377,7 @@ def main():
             "unit": "Tlane-op/s",
             "frac": round(achieved / VALU_PEAK_TLOPS, 4),
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel_ms": round(k_ms, 4),
             "kernel_variant": ("both views from one pass over the cost values (left map + the right view's partial %s)"
                                % ("keys, cost values as fp4 dot products on the matrix cores" if on_matrix_cores else "minima")) if both_views else "left view",

@@ -83,7 +83,7 @@ int svx_static_scratch_locate(svx_ctx *ctx);   // svx_dense.hip: finds this devi
 
 // Matrix-core form of the dense search on two-word descriptors (svx_dense_mx.hip).
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp);
-size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames, int max_disp);
+size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames, int words, int max_disp);
 int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp,
                         float *disparity, int write_border, float *partial);
 int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int words, int max_disp,

@@ -1075,15 +1075,23 @@ SVX_API int svx_dense_census9x7_subpixel_u8(svx_ctx *ctx, const uint8_t *left, c
 // Left and right disparity maps from one sweep over the cost values (sweep-eligible sizes only).
 // `partial` must hold both_views_partial_words() words.
 static bool both_views_eligible(int rows, int cols, int max_disp) { return !(max_disp > SW_DMASK + 1 || cols < SW_T + 4 || rows < 5); }
-static size_t both_views_partial_words(int rows, int cols, int n_frames, int max_disp) {
+// Sized for whichever kernel the search runs: the vector sweep leaves SW_PART minima per (row, x-block, 64-disparity
+// chunk), the matrix-core search one key per right column its workgroups cover (svx_mx_partial_words); on narrow frames
+// the latter is the larger of the two, and an option may change the choice between calls, so the larger one is taken.
+static size_t both_views_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames, int words, int max_disp) {
     const size_t n_xblocks = (cols - 4 + SW_T - 1) / SW_T, n_chunks = (max_disp + 63) >> 6;
-    return (size_t)n_frames * rows * n_xblocks * n_chunks * SW_PART;
+    size_t need = (size_t)n_frames * rows * n_xblocks * n_chunks * SW_PART;
+    if (both_views_on_matrix_cores(ctx, rows, cols, words, max_disp)) {
+        const size_t mx = svx_mx_partial_words(ctx, rows, cols, n_frames, words, max_disp);
+        if (mx > need) need = mx;
+    }
+    return need;
 }
 // The partial minima of a call are kept below 4 GiB: a batch whose minima would take more is swept in groups of frames
 // that share one buffer.  0 = not even one frame fits (or the size is not covered): one search per view instead.
-static int both_views_group_frames(int rows, int cols, int n_frames, int max_disp) {
+static int both_views_group_frames(const svx_ctx *ctx, int rows, int cols, int n_frames, int words, int max_disp) {
     if (!both_views_eligible(rows, cols, max_disp) || rows > 65535) return 0;
-    const size_t per_frame = both_views_partial_words(rows, cols, 1, max_disp);
+    const size_t per_frame = both_views_partial_words(ctx, rows, cols, 1, words, max_disp);
     const size_t fit = ((size_t)1 << 30) / per_frame;
     return (int)(fit < (size_t)n_frames ? fit : (size_t)n_frames);
 }
@@ -1095,8 +1103,8 @@ static int launch_both_views(svx_ctx *ctx, const uint32_t *cl, const uint32_t *c
     const size_t n = (size_t)rows * cols;
     const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
     // Two-word descriptors at up to 256 disparities: the cost values are formed on the matrix cores (at 128: 1.37 ms against
-    // 1.57 ms per 64 KITTI frames, and a cheaper merge); SVX_MX=0 keeps the vector sweep.  The partial keys take half
-    // the room of the vector sweep's partial minima, so the buffer sized for those is large enough.
+    // 1.57 ms per 64 KITTI frames, and a cheaper merge); SVX_MX=0 keeps the vector sweep.  `partial` holds
+    // both_views_partial_words() words for `group` frames, which covers either kernel's layout.
     const bool mx = both_views_on_matrix_cores(ctx, rows, cols, words, max_disp);
     for (int f0 = 0; f0 < n_frames; f0 += group) {
         const int nf = n_frames - f0 < group ? n_frames - f0 : group;
@@ -1136,14 +1144,14 @@ SVX_API int svx_dense_wta_both(svx_ctx *ctx, const uint32_t *census_left, const 
     SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_dense_wta_both: words must be 1 or 2");
     SVX_REQUIRE(ctx, rows <= 65535, SVX_ERR_UNSUPPORTED, "svx_dense_wta_both: too many rows per call");
     // sizes the sweep kernel does not cover: one search per view
-    const int group = both_views_group_frames(rows, cols, n_frames, max_disp);
+    const int group = both_views_group_frames(ctx, rows, cols, n_frames, words, max_disp);
     if (group == 0) {
         rc = launch_dense(ctx, census_left, census_right, rows, cols, n_frames, max_disp, disp_left, 1, words, 0);
         if (rc) return rc;
         return launch_dense(ctx, census_right, census_left, rows, cols, n_frames, max_disp, disp_right, 1, words, 1);
     }
     void *ws;
-    rc = svx_ws_reserve(ctx, both_views_partial_words(rows, cols, group, max_disp) * sizeof(uint32_t), &ws);
+    rc = svx_ws_reserve(ctx, both_views_partial_words(ctx, rows, cols, group, words, max_disp) * sizeof(uint32_t), &ws);
     if (rc) return rc;
     return launch_both_views(ctx, census_left, census_right, rows, cols, n_frames, words, max_disp, disp_left, disp_right, 0.f, group, (uint32_t *)ws);
 }
@@ -1157,10 +1165,10 @@ SVX_API int svx_probe_both_views_sweep(svx_ctx *ctx, const uint32_t *census_left
     rc = dense_args_ok(ctx, census_left, census_right, disp_left, rows, cols, n_frames, max_disp);
     if (rc) return rc;
     SVX_REQUIRE(ctx, words == 1 || words == 2, SVX_ERR_UNSUPPORTED, "svx_probe_both_views_sweep: words must be 1 or 2");
-    const int group = both_views_group_frames(rows, cols, n_frames, max_disp);
+    const int group = both_views_group_frames(ctx, rows, cols, n_frames, words, max_disp);
     SVX_REQUIRE(ctx, group > 0, SVX_ERR_UNSUPPORTED, "svx_probe_both_views_sweep: size not covered by the both-views sweep");
     void *ws;
-    rc = svx_ws_reserve(ctx, both_views_partial_words(rows, cols, group, max_disp) * sizeof(uint32_t), &ws);
+    rc = svx_ws_reserve(ctx, both_views_partial_words(ctx, rows, cols, group, words, max_disp) * sizeof(uint32_t), &ws);
     if (rc) return rc;
     return launch_both_views(ctx, census_left, census_right, rows, cols, n_frames, words, max_disp, disp_left, nullptr, 0.f, group, (uint32_t *)ws, true);
 }
@@ -1186,9 +1194,9 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     // SVX_OPT_LR_TWO_SWEEPS = 1 computes the right view with a second (mirrored) sweep instead of from the first one's cost values.
     const bool two_sweeps = svx_opt(ctx, SVX_OPT_LR_TWO_SWEEPS) == 1;
     // the partial minima of the one-sweep path take 80 words per (row, x-block, 64-disparity chunk) and frame
-    const int group = lr && !two_sweeps ? both_views_group_frames(rows, cols, n_frames, max_disp) : 0;
+    const int group = lr && !two_sweeps ? both_views_group_frames(ctx, rows, cols, n_frames, 2, max_disp) : 0;
     const bool both = group > 0;
-    const size_t part_words = both ? both_views_partial_words(rows, cols, group, max_disp) : 0;
+    const size_t part_words = both ? both_views_partial_words(ctx, rows, cols, group, 2, max_disp) : 0;
     void *ws;
     rc = svx_ws_reserve(ctx, (4 * n + part_words) * sizeof(uint32_t) + (lr && !both ? n * sizeof(float) : 0), &ws);
     if (rc) return rc;

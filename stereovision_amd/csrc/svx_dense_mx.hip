@@ -916,8 +916,8 @@ static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }
 static int mx_groups(int cols) { return (mx_xblocks(cols) + MX_W - 1) / MX_W; }                 // workgroups along x
 static int mx_keys_per_group(int tiles) { return 32 * (MX_W + tiles - 1); }
 
-size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames, int max_disp) {
-    const MxPlan plan = mx_plan(ctx, max_disp);
+size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames, int words, int max_disp) {
+    const MxPlan plan = mx_plan(ctx, max_disp, words);                // the plan the launch makes for the same arguments
     return (size_t)plan.passes * n_frames * rows * mx_groups(cols) * mx_keys_per_group(plan.tiles);
 }
 
@@ -1006,7 +1006,7 @@ SVX_API int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, cons
     SVX_REQUIRE(ctx, svx_mx_sweep_eligible(rows, cols, max_disp), SVX_ERR_UNSUPPORTED,
                 "svx_dense_wta_matrix: needs cols >= 36, rows >= 5, 1 <= max_disp <= 1024");
     if (!disp_right) return svx_launch_mx_sweep(ctx, census_left, census_right, rows, cols, n_frames, 2, max_disp, disp_left, 1, nullptr);
-    const size_t per_frame = svx_mx_partial_words(ctx, rows, cols, 1, max_disp);
+    const size_t per_frame = svx_mx_partial_words(ctx, rows, cols, 1, 2, max_disp);
     SVX_REQUIRE(ctx, per_frame * n_frames * sizeof(float) <= ((size_t)4 << 30), SVX_ERR_UNSUPPORTED, "svx_dense_wta_matrix: batch too large for one call");
     void *ws;
     rc = svx_ws_reserve(ctx, per_frame * n_frames * sizeof(float), &ws);

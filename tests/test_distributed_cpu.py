@@ -80,3 +80,27 @@ def _worker(rank, world, port, out_dir):
 def test_sharding_and_gathers(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): the parent starts the two ranks itself, before
+    anything touches a GPU, and rank 0 prints one JSON line with n_gpus 2 (--dry-run: the rank plumbing only, no GPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "3"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3 and lines[0]["dry_run"] is True
+
+
+def test_bench_launch_command_is_the_drivers_form():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(4, 29512, ["--gpus", "4", "--steps", "7"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29512" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert os.path.basename(cmd[-5]) == "bench.py"

@@ -287,6 +287,43 @@ def test_matrix_search_strip_lengths(ctx, strip_rows, D, words):
     assert torch.equal(mr, wr), (mr != wr).nonzero()[:5].tolist()
 
 
+@pytest.mark.parametrize("D", [48, 160])
+@pytest.mark.parametrize("words", [1, 2])
+def test_matrix_search_narrowest_frame_on_a_fresh_context(D, words):
+    """cols == 36, the narrowest frame the matrix-core search takes: its one workgroup leaves more partial keys per row
+    than the vector sweep's layout has room for (192 against 160 words at up to 64 disparities, 512 against 480 at 129..192),
+    so the workspace must be sized for the keys.  Two contexts whose workspace has never been larger than this request needs
+    (one for the both-views search, one for the fused entry); the grown workspace's slack is overrun after 12 frame-rows."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    rows, cols, frames = 64, 36, 3
+    ls, rs = synth.stereo_batch(rows, cols, min(D, cols // 2), frames, seed0=900 + D)
+    a = S.Context(0)
+    try:
+        dl, dr = dev(ls), dev(rs)
+        if words == 2:
+            hl, hr = np.stack([O.census9x7(x) for x in ls]), np.stack([O.census9x7(x) for x in rs])
+        else:
+            hl, hr = np.stack([O.census5x5(O.u8_to_s8(x)) for x in ls]), np.stack([O.census5x5(O.u8_to_s8(x)) for x in rs])
+        assert S.dense_kernel_name(rows, cols, words, D, True, a) == "dense_wta_mx_kernel"
+        ml, mr = a.dense_wta_both(dev_u32(hl), dev_u32(hr), D, words)
+        ml, mr = ml.cpu().numpy(), mr.cpu().numpy()
+        for f in range(frames):
+            assert np.array_equal(ml[f], O.dense_wta_words(hl[f], hr[f], D, 0)), f
+            assert np.array_equal(mr[f], O.dense_wta_words(hl[f], hr[f], D, 1)), f
+    finally:
+        a.close()
+    if words == 2:
+        b = S.Context(0)
+        try:
+            fused = b.dense_census9x7_lr(dl, dr, D, lr_threshold=1.0).cpu().numpy()
+            for f in range(frames):
+                want = O.lr_check(O.dense_wta_words(hl[f], hr[f], D, 0), O.dense_wta_words(hl[f], hr[f], D, 1), 1.0, -1.0)
+                assert np.array_equal(fused[f], want), f
+        finally:
+            b.close()
+
+
 @pytest.mark.parametrize("seed", [3, 4, 5, 6])
 def test_matrix_search_random_sizes(ctx, seed):
     """Fifteen random sizes per seed (widths that leave idle wavefronts or a shifted last x-block, forced short strips, every
