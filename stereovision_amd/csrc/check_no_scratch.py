@@ -23,8 +23,8 @@ def scratch_instructions(asm_path, names):
             continue
         if cur and re.match(r"^\s+\.size\s", line):
             cur = None
-        elif cur and re.match(r"^\s+scratch_", line):
-            counts[cur] += 1
+        elif cur and re.match(r"^\s+(scratch_|buffer_(load|store)\w*\s.*\bs\[0:3\])", line):
+            counts[cur] += 1                 # gfx950 reaches private memory with scratch_*; a buffer access through the private segment's descriptor counts as well
     return counts
 
 
@@ -36,6 +36,11 @@ def main():
         asm = args[i + 1]
         del args[i:i + 2]
     path, needles = args[0], args[1:]
+    if asm is not None:
+        try:
+            open(asm).close()
+        except OSError as e:
+            sys.exit("check_no_scratch: the assembly listing given with --asm cannot be read: %s" % e)
     name, spills, reserved, seen = None, [], {}, 0
     for line in open(path, errors="replace"):
         m = re.search(r"remark:.* Function Name: (\S+)", line) if "Function Name" in line else None
