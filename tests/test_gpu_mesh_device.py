@@ -181,3 +181,37 @@ def test_prior_from_device_mesh_equals_host_mesh(ctx):
     got, nt_d = ctx.mesh_plane_prior_device(dev(pts), dev(disp), dev(np.zeros((rows, cols), np.float32)))
     assert nt_h == nt_d
     assert np.array_equal(got.cpu().numpy(), want.cpu().numpy())
+
+
+@pytest.mark.parametrize("rows,cols,n,kind", [(368, 1232, 5000, "random"), (120, 160, 2500, "random"), (64, 64, 1200, "lattice"),
+                                              (368, 1232, 3000, "clustered"), (200, 300, 700, "border")])
+def test_device_mesh_against_the_oracle_definition(ctx, rows, cols, n, kind):
+    """The device triangulation checked by the ORACLE's definition checker (orc_delaunay_check: every triangle counter-clockwise
+    with an empty circumcircle by exact brute force, the triangles cover the hull exactly once), not only against the host
+    product's list: random sets, a lattice (every cell cocircular), clusters with empty areas, and points on the frame's
+    border lines (long fans around the hull points)."""
+    import oracle_lib as O
+    rng = np.random.default_rng(n + rows)
+    if kind == "lattice":
+        xs, ys = np.meshgrid(np.arange(2, cols - 2, 2), np.arange(2, rows - 2, 2))
+        pts = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+        pts = pts[rng.permutation(len(pts))[:n]]
+    elif kind == "clustered":
+        m = np.zeros((rows, cols), bool)
+        for _ in range(12):
+            cx, cy, r = rng.integers(0, cols), rng.integers(0, rows), rng.integers(15, 60)
+            m[max(cy - r, 0):cy + r, max(cx - r, 0):cx + r] = True
+        cand = np.flatnonzero(m)
+        idx = rng.choice(cand, size=min(n, len(cand)), replace=False)
+        pts = np.stack([idx % cols, idx // cols], 1).astype(np.int32)
+    elif kind == "border":
+        inner = unique_random(rng, rows, cols, n - 200)
+        edge = np.concatenate([np.stack([rng.integers(0, cols, 50), np.zeros(50, int)], 1), np.stack([rng.integers(0, cols, 50), np.full(50, rows - 1)], 1),
+                               np.stack([np.zeros(50, int), rng.integers(0, rows, 50)], 1), np.stack([np.full(50, cols - 1), rng.integers(0, rows, 50)], 1)])
+        pts = np.unique(np.concatenate([inner, edge]).astype(np.int32), axis=0)
+        pts = pts[rng.permutation(len(pts))]
+    else:
+        pts = unique_random(rng, rows, cols, n)
+    got = ctx.delaunay_device(dev(pts), rows, cols).cpu().numpy()
+    assert len(got) > 0
+    assert O.delaunay_check(pts, got) == 0

@@ -67,12 +67,14 @@ __global__ __launch_bounds__(64, 2) void k(float *out, int rows) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // left operands: ten 16-byte reads per row with the five columns in K (entering and leaving row), two with single-pixel tiles
+            auto left = [&](int o) { const uint4 v = lds[lane + 64 + ((o + r) & 255)]; return v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0}; };
             if (MODE == K5 || MODE == K5_NOSEL) {
-                an[t] = v8i{(int)lds[lane + 64 + ((t + r) & 255)].x, (int)lds[lane + 64 + ((t + r) & 255)].y, (int)lds[lane + 100 + ((t + r) & 255)].z, (int)lds[lane + 64 + ((t + r) & 127)].w, 0, 0, 0, 0};
-                an[(t + 1) % 5] = v8i{(int)lds[lane + 164 + ((t + r) & 255)].x, (int)lds[lane + 164 + ((t + r) & 255)].y, (int)lds[lane + 200 + ((t + r) & 255)].z, (int)lds[lane + 164 + ((t + r) & 127)].w, 0, 0, 0, 0};
+                an[t] = left(t);
+                an[(t + 1) % 5] = left(t + 100);
             } else if (t == 0) {
-                an[0] = v8i{(int)lds[lane + 64 + (r & 255)].x, (int)lds[lane + 64 + (r & 255)].y, (int)lds[lane + 100 + (r & 255)].z, (int)lds[lane + 64 + (r & 127)].w, 0, 0, 0, 0};
-                an[1] = v8i{(int)lds[lane + 164 + (r & 255)].x, (int)lds[lane + 164 + (r & 255)].y, (int)lds[lane + 200 + (r & 255)].z, (int)lds[lane + 164 + (r & 127)].w, 0, 0, 0, 0};
+                an[0] = left(0);
+                an[1] = left(100);
             }
             // --- the 5-column sum along the diagonal of tile rd
             float c[16];
