@@ -64,7 +64,8 @@ int svx_synchronize(svx_ctx *ctx);
  *   SVX_OPT_LR_TWO_SWEEPS    (SVX_LR_TWO_SWEEPS)   1 = the left-right entry points search each view with its own sweep
  *   SVX_OPT_SWEEP_WAVES      (SVX_SWEEP_OCC)       2 or 3 wavefronts per SIMD for the vector sweep (default 3)
  *   SVX_OPT_SWEEP_WAVES_BOTH (SVX_SWEEP_OCC_BOTH)  the same for the both-views vector sweep
- *   SVX_OPT_CENSUS97_PACKED  (SVX_CENSUS97_PACKED) 0 = one comparison per instruction in the 9x7 census tile kernel
+ *   SVX_OPT_CENSUS97_PACKED  (SVX_CENSUS97_PACKED) form of the 9x7 census tile kernel: 2 (default) three comparisons per subtraction (widths
+ *                                                  that are multiples of 4; others run form 1), 1 two per subtraction, 0 one comparison per instruction
  *   SVX_OPT_MX_STRIP_ROWS    (SVX_MX_STRIP_ROWS)   > 0 forces the output rows per strip of the matrix-core search
  *   SVX_OPT_STAGE_TIMES      (SVX_STAGE_TIMES)     1 = svx_high_perf_stereo synchronises at its stage marks and fills
  *                                                  svx_pipeline_stage_times (default 0: no synchronisation, times 0)

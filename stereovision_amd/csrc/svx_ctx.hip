@@ -70,7 +70,7 @@ static const struct { int builtin; const char *env; } svx_option_table[SVX_OPT_C
     /* SVX_OPT_LR_TWO_SWEEPS */ {0, "SVX_LR_TWO_SWEEPS"},
     /* SVX_OPT_SWEEP_WAVES */ {3, "SVX_SWEEP_OCC"},
     /* SVX_OPT_SWEEP_WAVES_BOTH */ {3, "SVX_SWEEP_OCC_BOTH"},
-    /* SVX_OPT_CENSUS97_PACKED */ {1, "SVX_CENSUS97_PACKED"},
+    /* SVX_OPT_CENSUS97_PACKED */ {2, "SVX_CENSUS97_PACKED"},
     /* SVX_OPT_MX_STRIP_ROWS */ {0, "SVX_MX_STRIP_ROWS"},
     /* SVX_OPT_STAGE_TIMES */ {0, "SVX_STAGE_TIMES"},
     /* SVX_OPT_PRIOR_BAND_RADIUS */ {0, "SVX_PRIOR_BAND_RADIUS"},

@@ -784,13 +784,135 @@ __device__ __forceinline__ void census9x7_tile_packed(const uint8_t *__restrict_
     }
 }
 
+// Third form of the tile kernel (widths that are multiples of 4): three comparisons per subtraction.  Three pixels of one
+// COLUMN (image rows r, r+1, r+2) sit in 9-bit fields of a dword, 0x100 + pixel each ("triple", built once per tile in LDS for
+// every row r and column); the centre is repeated in the three fields, and `triple - centres` leaves bit 8 of a field set exactly
+// when that neighbour is >= the centre (a field stays within 1..511, nothing is borrowed across fields).  Shifted right by the
+// column's place in the window and masked, the three bits land where descriptor order wants them: the nine columns of window
+// rows -3..-1 (and of rows +1..+3) fill 27 consecutive descriptor bits, index 9 row + column, with three instructions per
+// column (subtract, shift, and-or), i.e. one per comparison instead of the pair form's one and a half.  The window's own row
+// (eight comparisons) takes a byte compare and an add-with-carry each.  The collected bits say "not greater": one exclusive-or
+// per word turns them into the descriptor.
+constexpr int C97F_H = 16;                     // rows of a tile (a multiple of 4: four wavefronts share them; 8 and 32 measured no faster)
+constexpr int C97F_ROWS = C97F_H + 4;          // triples start at image rows y0-3 .. y0+C97F_H
+constexpr int C97F_PITCH = C97T_W + 8;         // one triple per column x0-4 .. x0+C97T_W+3
+
+#define C97_LE(SC, SN) asm("v_cmp_le_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #SC " src1_sel:BYTE_" #SN "\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \
+                           : "+v"(acc) : "v"(c), "v"(n) : "vcc")
+// acc = 2 acc + (byte SC of c <= byte SN of n)
+template <int SC, int SN>
+__device__ __forceinline__ void c97_le(uint32_t &acc, uint32_t c, uint32_t n) {
+    if constexpr (SC == 0 && SN == 0) C97_LE(0, 0); else if constexpr (SC == 0 && SN == 1) C97_LE(0, 1);
+    else if constexpr (SC == 0 && SN == 2) C97_LE(0, 2); else if constexpr (SC == 0 && SN == 3) C97_LE(0, 3);
+    else if constexpr (SC == 1 && SN == 0) C97_LE(1, 0); else if constexpr (SC == 1 && SN == 1) C97_LE(1, 1);
+    else if constexpr (SC == 1 && SN == 2) C97_LE(1, 2); else if constexpr (SC == 1 && SN == 3) C97_LE(1, 3);
+    else if constexpr (SC == 2 && SN == 0) C97_LE(2, 0); else if constexpr (SC == 2 && SN == 1) C97_LE(2, 1);
+    else if constexpr (SC == 2 && SN == 2) C97_LE(2, 2); else if constexpr (SC == 2 && SN == 3) C97_LE(2, 3);
+    else if constexpr (SC == 3 && SN == 0) C97_LE(3, 0); else if constexpr (SC == 3 && SN == 1) C97_LE(3, 1);
+    else if constexpr (SC == 3 && SN == 2) C97_LE(3, 2); else C97_LE(3, 3);
+}
+
+// The 27 "not greater" bits of one pixel against nine columns of three rows: t[P + j] is the triple of window column j.
+template <int P>
+__device__ __forceinline__ uint32_t c97_fields(const uint32_t (&t)[12], uint32_t centres) {
+    uint32_t acc;
+    asm("v_and_b32 %0, %1, %2" : "=v"(acc) : "s"(0x04020100u), "v"(t[P] - centres));
+#pragma unroll
+    for (int j = 1; j < 9; ++j)
+        asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc) : "v"((t[P + j] - centres) >> j), "s"(0x04020100u >> j));
+    return acc;
+}
+
+__device__ __forceinline__ void census9x7_tile_fields(const uint8_t *__restrict__ img_all, int rows, int cols, uint32_t *__restrict__ out_all, int frame) {
+    __shared__ uint32_t tile[(C97F_H + 6) * C97T_LROW];
+    __shared__ __attribute__((aligned(16))) uint32_t trip[C97F_ROWS * C97F_PITCH];
+    const long n = (long)rows * cols;
+    const uint8_t *img = img_all + (long)frame * n;
+    uint32_t *out = out_all + (long)frame * n * 2;
+    const int x0 = blockIdx.x * C97T_W, y0 = blockIdx.y * C97F_H;
+    for (int i = threadIdx.x; i < (C97F_H + 6) * C97T_LROW; i += 256) {
+        const int r = i / C97T_LROW, k = i - r * C97T_LROW;
+        const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * k;
+        uint32_t v = 0u;
+        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = *reinterpret_cast<const uint32_t *>(img + (long)gy * cols + gx);
+        tile[i] = v;
+    }
+    __syncthreads();
+    // triples of rows r, r+1, r+2 of the staged tile, four columns (one staged dword of each row) per step
+    for (int u = threadIdx.x; u < C97F_ROWS * (C97F_PITCH / 4); u += 256) {
+        const int r = u / (C97F_PITCH / 4), k = u - r * (C97F_PITCH / 4);
+        const uint32_t a = tile[r * C97T_LROW + k], b = tile[(r + 1) * C97T_LROW + k], c = tile[(r + 2) * C97T_LROW + k];
+        uint4 e;
+        e.x = ((a & 0xffu) << 18) | ((b & 0xffu) << 9) | (c & 0xffu) | 0x04020100u;
+        e.y = (((a >> 8) & 0xffu) << 18) | (((b >> 8) & 0xffu) << 9) | ((c >> 8) & 0xffu) | 0x04020100u;
+        e.z = (((a >> 16) & 0xffu) << 18) | (((b >> 16) & 0xffu) << 9) | ((c >> 16) & 0xffu) | 0x04020100u;
+        e.w = ((a >> 24) << 18) | ((b >> 24) << 9) | (c >> 24) | 0x04020100u;
+        *reinterpret_cast<uint4 *>(trip + r * C97F_PITCH + 4 * k) = e;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = x0 + lane * 4;
+    if (x >= cols) return;
+#pragma unroll
+    for (int j = 0; j < C97F_H / 4; ++j) {
+        const int r = wave * (C97F_H / 4) + j, y = y0 + r;            // staged row r is image row y - 3
+        if (y >= rows) break;
+        uint32_t hi[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
+        if (y >= 3 && y < rows - 3 && x >= 4 && x < cols - 4) {         // (the border columns are whole lanes: cols is a multiple of 4)
+            uint32_t up[12], dn[12], mid[3];
+            const uint4 *qa = reinterpret_cast<const uint4 *>(trip + r * C97F_PITCH + 4 * lane);          // rows y-3 .. y-1
+            const uint4 *qb = reinterpret_cast<const uint4 *>(trip + (r + 4) * C97F_PITCH + 4 * lane);    // rows y+1 .. y+3
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint4 va = qa[k], vb = qb[k];
+                up[4 * k] = va.x; up[4 * k + 1] = va.y; up[4 * k + 2] = va.z; up[4 * k + 3] = va.w;
+                dn[4 * k] = vb.x; dn[4 * k + 1] = vb.y; dn[4 * k + 2] = vb.z; dn[4 * k + 3] = vb.w;
+                mid[k] = tile[(r + 3) * C97T_LROW + lane + k];
+            }
+            auto pixel = [&](auto p_c) __attribute__((always_inline)) {
+                constexpr int P = decltype(p_c)::value;
+                const uint32_t cb = (mid[1] >> (8 * P)) & 0xffu;
+                const uint32_t c2 = (cb << 9) | cb, centres = (c2 << 9) | cb;
+                const uint32_t above = c97_fields<P>(up, centres), below = c97_fields<P>(dn, centres);
+                uint32_t left = 0u, right = 0u;
+                // the window's own row: columns x-4 .. x-1 and x+1 .. x+4 are bytes P .. P+3 and P+5 .. P+8 of the three staged dwords
+                c97_le<P, (P + 0) % 4>(left, mid[1], mid[(P + 0) / 4]);
+                c97_le<P, (P + 1) % 4>(left, mid[1], mid[(P + 1) / 4]);
+                c97_le<P, (P + 2) % 4>(left, mid[1], mid[(P + 2) / 4]);
+                c97_le<P, (P + 3) % 4>(left, mid[1], mid[(P + 3) / 4]);
+                c97_le<P, (P + 5) % 4>(right, mid[1], mid[(P + 5) / 4]);
+                c97_le<P, (P + 6) % 4>(right, mid[1], mid[(P + 6) / 4]);
+                c97_le<P, (P + 7) % 4>(right, mid[1], mid[(P + 7) / 4]);
+                c97_le<P, (P + 8) % 4>(right, mid[1], mid[(P + 8) / 4]);
+                hi[P] = ((above << 4) | left) ^ 0x7fffffffu;
+                lo[P] = ((right << 27) | below) ^ 0x7fffffffu;
+            };
+            pixel(std::integral_constant<int, 0>{}); pixel(std::integral_constant<int, 1>{});
+            pixel(std::integral_constant<int, 2>{}); pixel(std::integral_constant<int, 3>{});
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(out + ((long)y * cols + x) * 2);
+        o[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+        o[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+    }
+}
+
 // Both images of a batch of pairs in one launch: grid z = 2 x frames, the first half is the left batch.
-template <bool ALIGNED>
+// FIELDS: the three-comparisons-per-subtraction form (ALIGNED only).
+template <bool ALIGNED, bool FIELDS = false>
 __global__ __launch_bounds__(256) void census9x7_pair_kernel(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right, int rows, int cols,
                                                              long total_bytes, uint32_t *__restrict__ out_left, uint32_t *__restrict__ out_right, int n_frames) {
     const int z = blockIdx.z;
-    if (z < n_frames) census9x7_tile_packed<ALIGNED>(left, rows, cols, total_bytes, out_left, z);
-    else census9x7_tile_packed<ALIGNED>(right, rows, cols, total_bytes, out_right, z - n_frames);
+    if constexpr (FIELDS) {
+        if (z < n_frames) census9x7_tile_fields(left, rows, cols, out_left, z);
+        else census9x7_tile_fields(right, rows, cols, out_right, z - n_frames);
+    } else {
+        if (z < n_frames) census9x7_tile_packed<ALIGNED>(left, rows, cols, total_bytes, out_left, z);
+        else census9x7_tile_packed<ALIGNED>(right, rows, cols, total_bytes, out_right, z - n_frames);
+    }
+}
+
+__global__ __launch_bounds__(256) void census9x7_fields_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, uint32_t *__restrict__ out_all) {
+    census9x7_tile_fields(img_all, rows, cols, out_all, blockIdx.z);
 }
 
 template <bool ALIGNED, bool PACKED>
@@ -873,10 +995,13 @@ SVX_API int svx_census9x7_u8(svx_ctx *ctx, const uint8_t *img, uint32_t *census,
     const bool fast = (((uintptr_t)img & 3u) == 0) && (((uintptr_t)census & 15u) == 0);
     const long total_bytes = (long)rows * cols * n_frames;
     const dim3 tgrid(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97T_H), n_frames);
-    // SVX_OPT_CENSUS97_PACKED = 0 selects the one-comparison-per-instruction form of the tile kernel.
+    // SVX_OPT_CENSUS97_PACKED: 2 (default) three comparisons per subtraction where the width is a multiple of 4, 1 two per
+    // subtraction, 0 the one-comparison-per-instruction form of the tile kernel.
     const int packed = svx_opt(ctx, SVX_OPT_CENSUS97_PACKED);
     if (fast && cols % 4 == 0) {
-        if (packed) census9x7_tile_kernel<true, true><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
+        const dim3 fgrid(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97F_H), n_frames);
+        if (packed >= 2) census9x7_fields_kernel<<<fgrid, 256, 0, ctx->stream>>>(img, rows, cols, census);
+        else if (packed) census9x7_tile_kernel<true, true><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
         else census9x7_tile_kernel<true, false><<<tgrid, 256, 0, ctx->stream>>>(img, rows, cols, total_bytes, census);
         SVX_LAUNCH_CHECK(ctx, "census9x7_tile_kernel");
     } else if (fast && cols >= 9) {
@@ -900,7 +1025,9 @@ static int census9x7_pair(svx_ctx *ctx, const uint8_t *left, const uint8_t *righ
     }
     const long total_bytes = (long)rows * cols * n_frames;
     const dim3 grid(svx_cdiv(cols, C97T_W), svx_cdiv(rows, C97T_H), 2 * n_frames);
-    if (cols % 4 == 0) census9x7_pair_kernel<true><<<grid, 256, 0, ctx->stream>>>(left, right, rows, cols, total_bytes, cl, cr, n_frames);
+    if (cols % 4 == 0 && packed >= 2)
+        census9x7_pair_kernel<true, true><<<dim3(grid.x, svx_cdiv(rows, C97F_H), grid.z), 256, 0, ctx->stream>>>(left, right, rows, cols, total_bytes, cl, cr, n_frames);
+    else if (cols % 4 == 0) census9x7_pair_kernel<true><<<grid, 256, 0, ctx->stream>>>(left, right, rows, cols, total_bytes, cl, cr, n_frames);
     else census9x7_pair_kernel<false><<<grid, 256, 0, ctx->stream>>>(left, right, rows, cols, total_bytes, cl, cr, n_frames);
     SVX_LAUNCH_CHECK(ctx, "census9x7_pair_kernel");
     return SVX_OK;

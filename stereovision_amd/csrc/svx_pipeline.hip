@@ -330,9 +330,16 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     // computed points: the high-gradient set in raster order, then the mesh vertices
     *n_points = n_hg + n_sup;
     const int take_hg = std::min(n_hg, capacity), take_sup = std::max(0, std::min(n_sup, capacity - n_hg));
-    if (take_hg) SVX_HIP(ctx, hipMemcpyAsync(points_xy_host, pts, (size_t)take_hg * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (take_sup) SVX_HIP(ctx, hipMemcpyAsync(points_xy_host + 2 * (size_t)n_hg, sup_dev, (size_t)take_sup * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // through the context's pinned staging buffer (one DMA each, then a host copy): a transfer straight into the caller's
+    // pageable memory is staged by the runtime in small pieces and takes three times as long for the 2.5 MB of a KITTI frame
+    void *pin = nullptr;
+    if (take_hg + take_sup) SVX_TRY(svx_pinned_reserve(ctx, (size_t)(take_hg + take_sup) * 8, &pin));
+    int32_t *stage = (int32_t *)pin;
+    if (take_hg) SVX_HIP(ctx, hipMemcpyAsync(stage, pts, (size_t)take_hg * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (take_sup) SVX_HIP(ctx, hipMemcpyAsync(stage + 2 * (size_t)take_hg, sup_dev, (size_t)take_sup * 8, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (take_hg) memcpy(points_xy_host, stage, (size_t)take_hg * 8);
+    if (take_sup) memcpy(points_xy_host + 2 * (size_t)n_hg, stage + 2 * (size_t)take_hg, (size_t)take_sup * 8);
     clk.mark(9);
     return SVX_OK;
 }

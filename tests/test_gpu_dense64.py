@@ -30,14 +30,25 @@ def dev_u32(a):
 
 
 @pytest.mark.parametrize("rows,cols", [(32, 64), (7, 9), (6, 8), (37, 129), (48, 256), (50, 261), (1, 1), (16, 70), (375, 1242), (19, 1023),
-                                       (40, 514), (33, 10), (8, 11)])
-def test_census9x7(ctx, rows, cols):
+                                       (40, 514), (33, 10), (8, 11), (368, 1232), (7, 12), (23, 260), (17, 1028)])
+@pytest.mark.parametrize("form", [2, 1, 0])
+def test_census9x7(ctx, rows, cols, form):
+    """Every form of the tile kernel (three comparisons per subtraction, two per subtraction, one per instruction; widths that
+    are no multiple of 4 run form 1 in place of form 2) against the oracle, on noise, on an image of few levels (many ties)
+    and on one that holds the extreme values 0 and 255 side by side."""
+    import stereovision_amd as S
     rng = np.random.default_rng(rows * 100 + cols)
     imgs = rng.integers(0, 256, size=(3, rows, cols), dtype=np.uint8)
     imgs[1] = (imgs[1] // 64) * 64                                        # many ties
-    got = ctx.census9x7(dev(imgs)).cpu().numpy().view(np.uint32)
+    imgs[2] = np.where(rng.random((rows, cols)) < 0.5, 0, 255).astype(np.uint8)
+    imgs[2, ::3, ::5] = 254; imgs[2, 1::4, 2::3] = 1
+    ctx.set_option(S.OPT_CENSUS97_PACKED, form)
+    try:
+        got = ctx.census9x7(dev(imgs)).cpu().numpy().view(np.uint32)
+    finally:
+        ctx.set_option(S.OPT_CENSUS97_PACKED, 2)
     for f in range(3):
-        assert np.array_equal(got[f], O.census9x7(imgs[f]))
+        assert np.array_equal(got[f], O.census9x7(imgs[f])), (f, np.argwhere(got[f] != O.census9x7(imgs[f]))[:5])
 
 
 @pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (12, 40, 64), (30, 150, 128), (9, 21, 5), (5, 20, 8), (16, 300, 200),
