@@ -124,6 +124,11 @@ def cpu_baseline_9x7(left, right, D, n_frames_work, lr, lr_threshold):
     }, want, nrows
 
 
+def mx_passes(D):
+    """Launches of the matrix-core search for D disparities (svx_dense_mx.hip, mx_plan)."""
+    return 1 if D <= 128 else 1 + -(-(D - 128) // 160)
+
+
 def host_threads():
     """Worker threads for the all-cores CPU leg: the box's CPU share (OMP_NUM_THREADS there), within the affinity mask."""
     try:
@@ -349,7 +354,7 @@ def main():
         kernel_name = S.dense_kernel_name(rows, cols, words, D, both_views, ctx)
         on_matrix_cores = kernel_name == "dense_wta_mx_kernel"
         if on_matrix_cores:      # one key per right column a workgroup (four 32-column blocks) covers, per output row and pass of 128 disparities
-            part_bytes = 4.0 * 32 * (4 + (3 if D <= 64 else 5) - 1) * max(1, -(-D // 128)) * F * (rows - 4) * -(-((cols - 4 + 31) // 32) // 4) if both_views else 0.0
+            part_bytes = 4.0 * 32 * (4 + (3 if D <= 64 else 5) - 1) * mx_passes(D) * F * (rows - 4) * -(-((cols - 4 + 31) // 32) // 4) if both_views else 0.0
         else:
             part_bytes = 4.0 * 80 * F * (rows - 4) * ((cols - 4 + 15) // 16) * ((D + 63) // 64) if both_views else 0.0
         kernel_io_bytes = float(rows * cols * F * (2 * 4 * words + 4)) + part_bytes     # what this kernel itself must move
@@ -400,7 +405,7 @@ def main():
             # algorithmic work = per pix*disp one 5-column dot product over the descriptor bits for the census row that enters the
             # 5-row window and one for the row that leaves it = 2 * 5 * 64 multiply-adds = 1280 flop with 64-bit descriptors.  The vector-popcount
             # pricing used for the sweep kernel (2 lane-instructions per descriptor word and pix*disp) stays beside it.
-            tiles, passes = (3 if D <= 64 else 5), max(1, -(-D // 128))       # more than 128 disparities: passes of 128 (five tiles each)
+            tiles, passes = (3 if D <= 64 else 5), mx_passes(D)      # more than 128 disparities: passes whose five tiles lie side by side (160 right columns each)
             # strips as svx_launch_mx_sweep chooses them (a strip's first five rows have nothing leaving the window yet)
             slots = torch.cuda.get_device_properties(dev).multi_processor_count * 2     # workgroups of four wavefronts, two per CU
             per_strip = -(-((cols - 4 + 31) // 32) // 4) * F
@@ -418,7 +423,9 @@ def main():
             for p_ in range(passes):
                 for b in range(n_blocks):
                     xl0 = min(2 + 32 * b, cols - 34)
-                    dead = min(max(-(-(32 * (tiles - 1) - 29 + 128 * p_ - xl0) // 32), 0), 2) if tiles == 5 else 0
+                    dead = min(max(-(-(32 * (tiles - 1) - 29 + 160 * p_ - xl0) // 32), 0), 2) if tiles == 5 else 0
+                    if tiles == 5 and 160 * p_ + 97 - D >= 0:          # leading tiles whose disparities all lie beyond the range
+                        dead = min(max(dead, (160 * p_ + 97 - D) // 32 + 1), 2)
                     tile_units += tiles - dead
             mfma_count = tile_units * per_tile * F
             issued_flops = 2.0 * 32 * 32 * 64 * mfma_count

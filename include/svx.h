@@ -514,7 +514,7 @@ int svx_dense_kernel_choice(const svx_ctx *ctx, int rows, int cols, int words, i
 /* The search of svx_dense_wta / svx_dense_wta_both on two-word descriptors with the cost values formed on the matrix
  * cores (fp4 dot products of the expanded descriptors; denseCensusStereo/denseCensusStereo.cpp:87-131 generalised as
  * there): identical results.  Covers cols >= 36, rows >= 5, 1 <= max_disp <= 1024 (SVX_ERR_UNSUPPORTED otherwise); more
- * than 128 disparities are searched in passes of 128 whose winners' keys are merged.
+ * than 128 disparities are searched in passes (160 right columns each, side by side) whose winners' keys are merged.
  * disp_right may be NULL (left view only).  Border pixels are written as 0.  Asynchronous. */
 int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
                          int max_disp, float *disp_left, float *disp_right);

@@ -42,6 +42,7 @@ constexpr int MX_M = 32;                 // left columns per wavefront
 constexpr int MX_NBUF = 3;               // staged rows in flight: the one being read, the one being written, and one in between (see mx_strip)
 constexpr int MX_KROWS = 3;              // right view: key rows in LDS (the one being written out, the one being filled, and the next one the wavefronts ahead fill)
 constexpr float MX_NO_KEY = -4194304.0f; // below every key, admissible or not
+constexpr int MX_PASS_STEP = 160;        // more than 128 disparities: pass p takes the right columns 160 p further left (all columns of its five tiles, see mx_plan)
 
 template <int T, int WORDS = 2>
 struct MxGeom {
@@ -502,7 +503,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     using G = MxGeom<TG, WORDS>;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
-    const int r0 = xl0 - 32 * (T - 1) - d_base;      // right column of (computed) tile 0, lane 0 (this pass searches disparities d_base .. d_base + 32 (TG - 1) - 1)
+    const int r0 = xl0 - 32 * (T - 1) - d_base;      // right column of (computed) tile 0, lane 0 (this pass's tiles hold the right columns xl0 - 32 (TG - 1) - d_base .. + 32 TG - 1)
 
     // Accumulator element i of tile t is (left column xl0 + m, right column r0 + 32 t + n).  It starts at
     // (1023 - d) / 1024, so that the running window score carries its disparity tag below the integer part
@@ -524,7 +525,7 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
         for (int i = 0; i < 16; ++i) {
             const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
             const int d = xl0 + m - xr;
-            const bool in_range = d >= d_base && d < min(max_disp, d_base + 32 * (TG - 1));
+            const bool in_range = d >= 0 && d < max_disp;       // (the passes' right columns do not overlap: every pair is in one pass)
             const bool ok_l = xr >= 5, ok_r = xr >= 2 && xl0 + m <= cols - 6;          // what the left / the right view admits
             const bool ok = in_range && (BOTH ? ok_l || ok_r : ok_l);
             acc[t][i] = ok ? (float)(1023 - d) * (1.0f / 1024.0f) - (BOTH && !(ok_l && ok_r) ? 4096.0f : 0.0f) : -1048576.0f;
@@ -772,8 +773,9 @@ __device__ __forceinline__ void mx_strip_idle(uint4 *lds, const uint32_t *__rest
 // grid: (groups of MX_W x-blocks, strips, frames), MX_W wavefronts per block, one per x-block.  x-block b owns output
 // columns [xl0, xl0 + 32), xl0 = min(2 + 32 b, cols - 34) (the last block is shifted left to end at column cols-3);
 // a wavefront behind the last x-block only helps with the staging (mx_strip_idle).
-// Searches disparities d_base .. min(max_disp, d_base + 32 (T - 1)) - 1; a wider range takes several launches (pass_flags:
-// mx_reduce_tail).  Requires cols >= 36, rows >= 5.
+// Searches every pair (left column x, right column x - d), 0 <= d < max_disp, whose right column lies in the x-block's T tiles,
+// xl0 - 32 (T - 1) - d_base .. xl0 + 31 - d_base; a wider range takes several launches whose tiles lie side by side
+// (d_base = 0, 160, ...; pass_flags: mx_reduce_tail).  Requires cols >= 36, rows >= 5.
 // BOTH: also stores, for every output row and workgroup, the right view's best key of each of the 32 (MX_W + T - 1) right
 // columns the workgroup's tiles cover, over the workgroup's left columns: partial[frame][row][workgroup][NKEYS]
 // (svx_mx_right_disparity merges the workgroups that reach a right pixel).
@@ -805,8 +807,13 @@ __global__ __launch_bounds__(64 * MX_W, T <= 5 ? 2 : 1) void dense_wta_mx_kernel
     // x-blocks at the frame's left border (and, in a later pass, left of its first disparity): tile u holds right columns
     // xl0 - 32 (T - 1) - d_base + 32 u .. + 31, and the first tiles, whose columns all lie left of column 2, hold no admissible pair.
     // With five tiles up to two of them are not computed (three is the fewest the row's timetable takes).
+    // Likewise the first tiles of a search's last pass when every disparity of theirs is max_disp or more (tile u: at least d_base + 97 - 32 u).
     int dead = 0;
-    if constexpr (T == 5) dead = min(max((32 * (T - 1) - 29 + d_base - xl0 + 31) / 32, 0), 2);
+    if constexpr (T == 5) {
+        dead = min(max((32 * (T - 1) - 29 + d_base - xl0 + 31) / 32, 0), 2);
+        const int beyond = d_base + 97 - max_disp;
+        if (beyond >= 0) dead = min(max(dead, beyond / 32 + 1), 2);
+    }
     if (bx_wave > n_xblocks - 1) mx_strip_idle<T, WORDS, BOTH>(lds, cl, cr, cols, d_base, xl0_wg, y_lo, n_rows, tid, part_row0, part_stride);
     else if (T == 5 && dead == 2) {
         if constexpr (T == 5) mx_strip<3, WORDS, BOTH, 5>(lds, cl, cr, cols, max_disp, d_base, pass_flags, xl0, xl0_wg, own_from, y_lo, n_rows, tid, disp, part_row0, part_stride);
@@ -835,7 +842,10 @@ __device__ __forceinline__ float svx_mx_right_key(const float *__restrict__ prow
     constexpr int GW = 32 * MX_W, NK = MxGeom<T>::NKEYS, K = (NK + GW - 1) / GW;
     float best = MX_NO_KEY;
     const int a = xs >= 2 ? (xs - 2) / GW : -1;
-    if (a >= 0 && a + K - 1 < n_groups - 1) {
+    // (the last group is shifted left to end at the frame's last column, so it reaches further left than a regular group in its
+    // place would: where it can hold xs, the general form below looks at it as well)
+    const int last_from = min(2 + (n_groups - 1) * GW, cols - 2 - MX_M) - 32 * (T - 1);
+    if (a >= 0 && a + K - 1 < n_groups - 1 && xs < last_from) {
         // all regular groups (X = 2 + GW g): group a + k holds xs in slot (xs - 2) % GW + 32 (T - 1) - GW k while that is not negative
         const int slot = (xs - 2) - a * GW + 32 * (T - 1);
         const float *p = prow + (long)a * NK + slot;
@@ -860,7 +870,7 @@ __device__ __forceinline__ float svx_mx_right_key(const float *__restrict__ prow
 template <int T>
 __device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, long pass_stride, int n_pass, int xr, int cols, int n_groups) {
     float best = svx_mx_right_key<T>(prow, xr, cols, n_groups);
-    for (int p = 1; p < n_pass; ++p) best = fmaxf(best, svx_mx_right_key<T>(prow + p * pass_stride, xr + p * 32 * (T - 1), cols, n_groups));
+    for (int p = 1; p < n_pass; ++p) best = fmaxf(best, svx_mx_right_key<T>(prow + p * pass_stride, xr + p * MX_PASS_STEP, cols, n_groups));
     return mx_decode(best);
 }
 
@@ -903,14 +913,18 @@ __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX_M + 4 && rows >= 5 && max_disp >= 1 && max_disp <= MX_MAX_DISP; }
 
 // Tiles per wavefront and launches per search: up to 64 / 128 disparities three / five tiles in one pass; wider ranges in
-// passes of 128 disparities with five tiles (two wavefronts per SIMD; nine tiles in one pass leave room for one, which is
-// slower per disparity), unless SVX_OPT_MX_WIDE_TILES asks for the nine-tile kernel at up to 256.
+// passes of five tiles (two wavefronts per SIMD; nine tiles in one pass leave room for one, which is slower per disparity),
+// unless SVX_OPT_MX_WIDE_TILES asks for the nine-tile kernel at up to 256.  The passes' tiles lie side by side: pass p holds the
+// right columns xl0 - 128 - 160 p .. xl0 + 31 - 160 p, so only the first pass (d < 0) and the last (d >= max_disp) compute pairs
+// outside the band, where passes of 128 disparities each would compute a half-empty first and last tile per pass: left column
+// xl0 + m has reached disparity 128 + 160 p + m after pass p, which makes 1 + ceil((max_disp - 128) / 160) passes (256: 9 tiles
+// instead of 10; 512: 18 instead of 20, three of the last pass's five being skipped or dead; 1024: 34 instead of 40).
 struct MxPlan { int tiles, passes; };
 static MxPlan mx_plan(const svx_ctx *ctx, int max_disp, int words = 2) {
     if (max_disp <= 64) return {3, 1};
     if (max_disp <= 128) return {5, 1};
     if (max_disp <= 256 && words == 2 && svx_opt(ctx, SVX_OPT_MX_WIDE_TILES) == 1) return {9, 1};
-    return {5, (max_disp + 127) / 128};
+    return {5, 1 + (max_disp - 128 + MX_PASS_STEP - 1) / MX_PASS_STEP};
 }
 static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }
 static int mx_groups(int cols) { return (mx_xblocks(cols) + MX_W - 1) / MX_W; }                 // workgroups along x
@@ -950,7 +964,7 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     const int nb = mx_xblocks(cols);
     const size_t pass_words = (size_t)n_frames * rows * n_groups * mx_keys_per_group(T);
     for (int p = 0; p < plan.passes; ++p) {
-        const int d_base = p * 32 * (T - 1), flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes ? 2 : 0);
+        const int d_base = p * MX_PASS_STEP, flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes ? 2 : 0);
         const int wb = p + 1 == plan.passes ? write_border : 0;
         float *part = partial ? partial + p * pass_words : nullptr;
 #define MX_LAUNCH(TT, WW, BB, PART) dense_wta_mx_kernel<TT, WW, BB><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, PART)

@@ -19,7 +19,7 @@ bad = 0
 for case in range(n_cases):
     cols = int(rng.choice([rng.integers(36, 80), rng.integers(80, 400), rng.integers(400, 1400)]))
     rows = int(rng.integers(5, 90))
-    D = int(rng.choice([rng.integers(1, 65), rng.integers(65, 129), rng.integers(129, 400)]))
+    D = int(rng.choice([rng.integers(1, 65), rng.integers(65, 129), rng.integers(129, 400), rng.integers(400, 1025)]))
     words = int(rng.integers(1, 3))
     frames = int(rng.integers(1, 4))
     strip = int(rng.choice([0, 0, rng.integers(1, 12)]))
