@@ -166,7 +166,7 @@ struct MxState {
     bool t_any[2], t_left[2], t_has[2];                      // those rounds: this wavefront takes part / stages left words / this lane holds a word
     bool own;                                                // this lane's left column belongs to this x-block alone (the last block is shifted over its neighbour)
     float best[16], ra[8], rb[4], rc[4];                     // left view: winners of a row being folded / reduced
-    float lift_r[T], lift_l;                                 // both views: what the right view adds to a tile's best key and the left view to its winner (0 or 4096, see mx_strip)
+    float lift_l;                                            // both views: what the left view adds to its winner (0 or 4096, see mx_strip)
     float *out_row;                                          // left map: the x-block's first pixel of the row being written (the same for every lane) ...
     uint32_t out_off;                                        // ... and this lane's byte offset from it
     long out_stride;
@@ -207,8 +207,7 @@ __device__ __forceinline__ void mx_right_b(const mx_v16f (&acc)[T], const MxStat
     x[4] = mx_max3(mx_elem_r<T>(acc, st, U, 12), mx_elem_r<T>(acc, st, U, 13), mx_elem_r<T>(acc, st, U, 14));
     x[0] = mx_max3(x[0], x[1], x[2]);
     x[0] = mx_max3(x[0], x[3], x[4]);
-    x[0] = mx_max(x[0], mx_elem_r<T>(acc, st, U, 15));
-    x[0] += st.lift_r[U];                                    // right columns 2..4: every pair of theirs starts 4096 lower (mx_strip)
+    x[0] = mx_max(x[0], mx_elem_r<T>(acc, st, U, 15));       // (right columns 2..4 leave 4096 too low, see mx_strip: svx_mx_right_disparity lifts them)
 }
 // Both lane halves hold left columns of the same right column; the workgroup's other x-blocks cover it as well: all of
 // them meet in the key row (a 4-byte LDS operation serves the two halves in different cycles, so equal addresses do not collide).
@@ -512,15 +511,15 @@ __device__ __forceinline__ void mx_strip(uint4 *lds, const uint32_t *__restrict_
     // only ONE of the views admits (right columns 2..4; left columns cols-5..cols-3) starts 4096 lower (still exact: 23
     // significant bits, keys stay above -8192).  The other view never prefers it to a pair of its own (those lie above
     // -1600) and decodes it as "no disparity" when it has none (mx_decode).  The view that admits it gets the true key
-    // back by adding 4096 AFTER its reduction: such a right column holds nothing but lowered or inadmissible pairs, so the
-    // right view lifts the tile's best key of that lane (lift_r, one addition per tile), and such a left column likewise,
-    // so the left view lifts its winner (lift_l, one addition per row).  No accumulator read pays for the frame's borders.
+    // back by adding 4096 AFTER its reduction: such a right column holds nothing but lowered or inadmissible pairs in every
+    // x-block and pass, so its merged key is lifted where it is decoded (svx_mx_right_disparity: the search spends nothing on
+    // it), and such a left column likewise, so the left view lifts its winner (lift_l, one addition per row).  No accumulator
+    // read pays for the frame's borders.
     mx_v16f acc[T];
     MxState<T, TG> st;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int xr = r0 + 32 * t + n;
-        st.lift_r[t] = BOTH && xr < 5 ? 4096.0f : 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -871,7 +870,9 @@ template <int T>
 __device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, long pass_stride, int n_pass, int xr, int cols, int n_groups) {
     float best = svx_mx_right_key<T>(prow, xr, cols, n_groups);
     for (int p = 1; p < n_pass; ++p) best = fmaxf(best, svx_mx_right_key<T>(prow + p * pass_stride, xr + p * MX_PASS_STEP, cols, n_groups));
-    return mx_decode(best);
+    // right columns 2..4 are admitted by the right view only: each of their pairs started 4096 lower (mx_strip), so the
+    // best of them is lifted here (a column without any pair stays far below the threshold of mx_decode)
+    return mx_decode(xr < 5 ? best + 4096.0f : best);
 }
 
 template <int T>
