@@ -28,7 +28,28 @@ struct svx_ctx {
     hipEvent_t pinned_read;                 // recorded behind the last asynchronous copy out of `pinned`
     bool pinned_busy;
     int mesh_left_over, mesh_left_first;    // svx_mesh_dev.hip: points of the last device triangulation that needed the pass over all points / a second look
+    struct svx_mail *mail_host, *mail_dev;  // a few words of host memory that kernels write to directly (svx_mail_next)
+    unsigned mail_seq;
+    hipStream_t side_stream;                // svx_high_perf_stereo: copies that run beside the frame's kernels (svx_side_copy_to_host)
+    hipEvent_t side_ready, side_done;
+    void *side_pin;                         // pinned host memory those copies land in
+    size_t side_pin_bytes;
+    bool side_busy;
 };
+
+// Counts a kernel leaves for the host without a copy: host memory the device writes straight into.  The host hands the kernel
+// the device address and a sequence number (svx_mail_next); the kernel stores its values, then the number (svx_mail_post, after
+// every storing thread's __threadfence_system and a barrier); svx_mail_wait returns when the number has arrived, which can be
+// well before the stream drains.  It keeps an eye on the stream, so a launch that failed ends the wait.
+struct svx_mail { unsigned seq; unsigned v[31]; };
+int svx_mail_next(svx_ctx *ctx, svx_mail **dev, unsigned *seq);
+int svx_mail_wait(svx_ctx *ctx, unsigned seq, const unsigned **values);
+// A copy to the host beside the stream's work: pinned memory of its own (svx_side_reserve, which first waits for a copy still in
+// flight), a copy that starts when the work queued on the context's stream so far is done and runs on a stream of its own
+// (svx_side_copy_to_host), and the wait for it (svx_side_wait).
+int svx_side_reserve(svx_ctx *ctx, size_t bytes, void **host);
+int svx_side_copy_to_host(svx_ctx *ctx, void *host, const void *dev, size_t bytes);
+int svx_side_wait(svx_ctx *ctx);
 
 // Default of an option: its environment variable when set, else the built-in value.
 int svx_option_default(int option);
@@ -90,6 +111,11 @@ int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, 
                         float *disp_left, float *disp_right, float lr_threshold);
 
 // ---- device helpers -------------------------------------------------------
+
+__device__ __forceinline__ void svx_mail_post(svx_mail *m, unsigned seq) {
+    __threadfence_system();
+    __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Flat-guard read: index into one contiguous frame of n elements, 0 outside.
 __device__ __forceinline__ uint32_t ld_guard_u32(const uint32_t *__restrict__ img, long n, long idx) {

@@ -3,7 +3,7 @@
 // A predicate pred(x, y, frame) selects pixels; the selected ones are handed to emit(slot, x, y, frame)
 // with slot = their rank in (frame, y, x) order, which is the order a sequential double loop over the
 // image pushes them into a vector.  Three launches: per-line counts, one-block exclusive scan over the
-// lines, per-line ranked write.  The predicate is evaluated twice, so it should be a cheap read.
+// lines (which also hands the per-frame totals to the host), per-line ranked write.  The predicate is evaluated twice, so it should be a cheap read.
 #pragma once
 #include "svx_common.hpp"
 
@@ -21,8 +21,10 @@ __global__ __launch_bounds__(256) void compact_count_kernel(Pred pred, int rows,
     if (threadIdx.x == 0) line_count[line] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 }
 
-// In-place exclusive scan of line_count[0..n_lines) by one block; line_count[n_lines] receives the total.
-__global__ __launch_bounds__(1024) void compact_scan_kernel(unsigned *__restrict__ line_count, int n_lines) {
+// In-place exclusive scan of line_count[0..n_lines) by one block; line_count[n_lines] receives the total.  Then the frames'
+// offsets (frame f starts at line f * rows): frame_off[0 .. n_frames], and to the host as well when `mail` is given (n_frames < 31).
+__global__ __launch_bounds__(1024) void compact_scan_kernel(unsigned *__restrict__ line_count, int n_lines, int rows, int n_frames,
+                                                            unsigned *__restrict__ frame_off, svx_mail *mail, unsigned seq) {
     __shared__ unsigned wave_tot[16];
     __shared__ unsigned carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -46,11 +48,22 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(unsigned *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) line_count[n_lines] = carry;
+    __syncthreads();
+    for (int f = threadIdx.x; f <= n_frames; f += 1024) {
+        const unsigned off = line_count[(long)f * rows];
+        frame_off[f] = off;
+        if (mail) { mail->v[f] = off; __threadfence_system(); }
+    }
+    if (mail) {
+        __syncthreads();
+        if (threadIdx.x == 0) svx_mail_post(mail, seq);
+    }
 }
 
-// In-place exclusive scan of v[0..n) by one workgroup, four consecutive values per thread and round (one 16-byte
-// load a lane); v[n] receives the total.  v must be 16-byte aligned.
-__global__ __launch_bounds__(1024) void scan4_kernel(unsigned *__restrict__ v, int n) {
+// Exclusive scan of src[0..n) into v[0..n) by one workgroup (src == v: in place), four consecutive values per thread and round
+// (one 16-byte load a lane); v[n] receives the total, and so does the host (mail->v[0]) when `mail` is given.  v and src must be
+// 16-byte aligned.
+__global__ __launch_bounds__(1024) void scan4_kernel(unsigned *v, int n, const unsigned *src, svx_mail *mail, unsigned seq) {
     __shared__ unsigned wave_tot[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned carry = 0;
@@ -58,11 +71,11 @@ __global__ __launch_bounds__(1024) void scan4_kernel(unsigned *__restrict__ v, i
     for (int base = 0; base < n; base += 4096, buf ^= 1) {
         const int i0 = base + 4 * (int)threadIdx.x;
         uint4 x = make_uint4(0, 0, 0, 0);
-        if (i0 + 3 < n) x = *(const uint4 *)(v + i0);
+        if (i0 + 3 < n) x = *(const uint4 *)(src + i0);
         else {
-            if (i0 < n) x.x = v[i0];
-            if (i0 + 1 < n) x.y = v[i0 + 1];
-            if (i0 + 2 < n) x.z = v[i0 + 2];
+            if (i0 < n) x.x = src[i0];
+            if (i0 + 1 < n) x.y = src[i0 + 1];
+            if (i0 + 2 < n) x.z = src[i0 + 2];
         }
         const unsigned sum = x.x + x.y + x.z + x.w;
         unsigned incl = sum;                              // inclusive scan of the threads' sums inside the wavefront
@@ -89,7 +102,10 @@ __global__ __launch_bounds__(1024) void scan4_kernel(unsigned *__restrict__ v, i
         carry += all;
     }
     __syncthreads();                                      // every thread has read what it scans before the total lands behind it
-    if (threadIdx.x == 0) v[n] = carry;
+    if (threadIdx.x == 0) {
+        v[n] = carry;
+        if (mail) { mail->v[0] = carry; svx_mail_post(mail, seq); }
+    }
 }
 
 template <class Pred, class Emit>
@@ -121,44 +137,46 @@ __global__ __launch_bounds__(256) void compact_write_kernel(Pred pred, Emit emit
     }
 }
 
-__global__ void compact_frame_offsets_kernel(const unsigned *__restrict__ line_off, int rows, int n_frames, unsigned *__restrict__ frame_off) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f <= n_frames) frame_off[f] = line_off[(long)f * rows];
-}
-
 // Device bytes svx_compact_raster needs at `area`.
 static inline size_t svx_compact_bytes(int rows, int n_frames) {
     return ((size_t)rows * n_frames + 1 + (size_t)n_frames + 1) * sizeof(unsigned);
 }
 
 // Runs the launches on the context's stream and returns the per-frame offsets
-// (frame_offsets_host[f] .. frame_offsets_host[f+1] are frame f's slots; n_frames+1 entries) after a
-// stream synchronisation.  Slots >= capacity are counted but not emitted.  `area` is device memory of
+// (frame_offsets_host[f] .. frame_offsets_host[f+1] are frame f's slots; n_frames+1 entries) as soon as the
+// scan has produced them (the ranked write may still be running on the stream).  Slots >= capacity are counted but not emitted.  `area` is device memory of
 // svx_compact_bytes(rows, n_frames) bytes that the caller reserved from the context's workspace.
 template <class Pred, class Emit>
 int svx_compact_raster(svx_ctx *ctx, void *area, int rows, int cols, int n_frames, Pred pred, Emit emit, int capacity,
                        int *frame_offsets_host, const char *what) {
     const long n_lines = (long)rows * n_frames;
     if (n_lines > 0x7fffffffL / 2) return svx_fail(ctx, SVX_ERR_UNSUPPORTED, "%s: too many image lines", what);
-    void *pin;
-    int rc = svx_pinned_reserve(ctx, (size_t)(n_frames + 1) * sizeof(unsigned), &pin);
-    if (rc) return rc;
     unsigned *line_off = (unsigned *)area;
+    unsigned *frame_off = line_off + n_lines + 1;
+    // the offsets reach the host straight from the scan (up to 30 frames), or by a copy behind the last launch
+    svx_mail *mail = nullptr;
+    unsigned seq = 0;
+    void *pin = nullptr;
+    int rc = n_frames < 31 ? svx_mail_next(ctx, &mail, &seq) : svx_pinned_reserve(ctx, (size_t)(n_frames + 1) * sizeof(unsigned), &pin);
+    if (rc) return rc;
     compact_count_kernel<Pred><<<(unsigned)n_lines, 256, 0, ctx->stream>>>(pred, rows, cols, line_off);
     SVX_LAUNCH_CHECK(ctx, what);
-    compact_scan_kernel<<<1, 1024, 0, ctx->stream>>>(line_off, (int)n_lines);
+    compact_scan_kernel<<<1, 1024, 0, ctx->stream>>>(line_off, (int)n_lines, rows, n_frames, frame_off, mail, seq);
     SVX_LAUNCH_CHECK(ctx, what);
     if (capacity > 0) {
         compact_write_kernel<Pred, Emit><<<(unsigned)n_lines, 256, 0, ctx->stream>>>(pred, emit, rows, cols, line_off, (unsigned)capacity);
         SVX_LAUNCH_CHECK(ctx, what);
     }
-    // Frame f starts at line f*rows.
-    unsigned *frame_off = line_off + n_lines + 1;
-    compact_frame_offsets_kernel<<<svx_cdiv(n_frames + 1, 256), 256, 0, ctx->stream>>>(line_off, rows, n_frames, frame_off);
-    SVX_LAUNCH_CHECK(ctx, what);
-    SVX_HIP(ctx, hipMemcpyAsync(pin, frame_off, (size_t)(n_frames + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int f = 0; f <= n_frames; ++f) frame_offsets_host[f] = (int)((unsigned *)pin)[f];
+    const unsigned *got = nullptr;
+    if (mail) {
+        rc = svx_mail_wait(ctx, seq, &got);
+        if (rc) return rc;
+    } else {
+        SVX_HIP(ctx, hipMemcpyAsync(pin, frame_off, (size_t)(n_frames + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        got = (const unsigned *)pin;
+    }
+    for (int f = 0; f <= n_frames; ++f) frame_offsets_host[f] = (int)got[f];
     return SVX_OK;
 }
 

@@ -64,6 +64,80 @@ int svx_pinned_reserve(svx_ctx *ctx, size_t bytes, void **out) {
     return SVX_OK;
 }
 
+int svx_mail_next(svx_ctx *ctx, svx_mail **dev, unsigned *seq) {
+    if (!ctx->mail_host) {
+        void *h = nullptr, *d = nullptr;
+        hipError_t e = hipHostMalloc(&h, sizeof(svx_mail), hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) {
+            if (h) (void)hipHostFree(h);
+            return svx_fail(ctx, SVX_ERR_NOMEM, "host memory for the kernels' counts: %s", hipGetErrorString(e));
+        }
+        memset(h, 0, sizeof(svx_mail));
+        ctx->mail_host = (svx_mail *)h;
+        ctx->mail_dev = (svx_mail *)d;
+        ctx->mail_seq = 0;
+    }
+    *dev = ctx->mail_dev;
+    *seq = ++ctx->mail_seq;
+    if (*seq == 0) *seq = ++ctx->mail_seq;          // (0 is what the memory starts with)
+    return SVX_OK;
+}
+
+int svx_mail_wait(svx_ctx *ctx, unsigned seq, const unsigned **values) {
+    const unsigned *at = &ctx->mail_host->seq;
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(at, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xfff) == 0) {                  // now and then: is the stream still at work?
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipErrorNotReady) continue;
+            if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_HIP, "waiting for a kernel's counts: %s", hipGetErrorString(e));
+            if (__atomic_load_n(at, __ATOMIC_ACQUIRE) == seq) break;
+            return svx_fail(ctx, SVX_ERR_HIP, "a kernel ended without leaving its counts");
+        }
+    }
+    *values = ctx->mail_host->v;
+    return SVX_OK;
+}
+
+int svx_side_wait(svx_ctx *ctx) {
+    if (ctx->side_busy) {
+        SVX_HIP(ctx, hipEventSynchronize(ctx->side_done));
+        ctx->side_busy = false;
+    }
+    return SVX_OK;
+}
+
+int svx_side_reserve(svx_ctx *ctx, size_t bytes, void **host) {
+    int rc = svx_side_wait(ctx);
+    if (rc) return rc;
+    if (!ctx->side_stream) {
+        SVX_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ready, hipEventDisableTiming));
+        SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
+    }
+    if (bytes > ctx->side_pin_bytes) {
+        if (ctx->side_pin) SVX_HIP(ctx, hipHostFree(ctx->side_pin));
+        ctx->side_pin = nullptr;
+        ctx->side_pin_bytes = 0;
+        const size_t want = bytes + (bytes >> 2) + 4096;
+        const hipError_t e = hipHostMalloc(&ctx->side_pin, want, hipHostMallocDefault);
+        if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "pinned memory of %zu bytes: %s", want, hipGetErrorString(e));
+        ctx->side_pin_bytes = want;
+    }
+    *host = ctx->side_pin;
+    return SVX_OK;
+}
+
+int svx_side_copy_to_host(svx_ctx *ctx, void *host, const void *dev, size_t bytes) {
+    SVX_HIP(ctx, hipEventRecord(ctx->side_ready, ctx->stream));
+    SVX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ready, 0));
+    SVX_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->side_stream));
+    SVX_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
+    ctx->side_busy = true;
+    return SVX_OK;
+}
+
 // Options: built-in default and the environment variable that overrides it when a context is created.
 static const struct { int builtin; const char *env; } svx_option_table[SVX_OPT_COUNT] = {
     /* SVX_OPT_MATRIX_CORES */ {-1, "SVX_MX"},
@@ -166,6 +240,14 @@ SVX_API int svx_destroy(svx_ctx *ctx) {
     if (ctx->tri) (void)hipFree(ctx->tri);
     if (ctx->pinned_read) (void)hipEventDestroy(ctx->pinned_read);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->mail_host) (void)hipHostFree(ctx->mail_host);
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+        (void)hipEventDestroy(ctx->side_ready);
+        (void)hipEventDestroy(ctx->side_done);
+    }
+    if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     delete ctx;
     return SVX_OK;
 }

@@ -31,7 +31,8 @@ struct DPt { int x, y, id; };
 __device__ __forceinline__ DPt unpack(int2 c) { DPt p; p.x = c.x & 0xffff; p.y = (int)((unsigned)c.x >> 16); p.id = c.y; return p; }
 
 // Coordinates lie in [0, 8192): differences below 2^13, cross products below 2^27 (32-bit), the circle determinant below 2^57.
-__device__ __forceinline__ int d_orient(const DPt &a, const DPt &b, const DPt &c) { return (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x); }
+// (the factors fit 24 bits: the full-rate multiplier)
+__device__ __forceinline__ int d_orient(const DPt &a, const DPt &b, const DPt &c) { return __mul24(b.x - a.x, c.y - a.y) - __mul24(b.y - a.y, c.x - a.x); }
 
 // > 0 when d lies inside the circle through a, b, c (counter-clockwise), cocircular cases by the rule of svx_mesh.hip
 // (in_circle_small, in_circle_tie there): never 0 for four distinct positions.
@@ -66,14 +67,78 @@ struct Circle {
     }
 };
 
+// The smallest value of x over the wavefront, the same in every lane: inside the rows of 16 lanes by DPP (lane ^ 1, lane ^ 2,
+// mirrored halves, mirrored row), the four rows through scalar registers.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+    x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));     // quad_perm:[1,0,3,2]
+    x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));     // quad_perm:[2,3,0,1]
+    x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));    // row_half_mirror
+    x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));    // row_mirror
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)x, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)x, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)x, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+// Running total of x over the wavefront's lanes, this lane included: inside the rows of 16 lanes by DPP shifts, then the
+// last lane of a row (of the first two rows) is added to the rows behind it.
+__device__ __forceinline__ unsigned wave_scan_u32(unsigned x) {
+    const int v = (int)x;
+    int t = v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);                    // row_shr:1
+    t += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);                            // row_shr:2
+    t += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true);                            // row_shr:3
+    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xe, false);                           // row_shr:4, lanes 4..15 of a row
+    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xc, false);                           // row_shr:8, lanes 8..15
+    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, false);                           // row_bcast:15, rows 1 and 3
+    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, false);                           // row_bcast:31, rows 2 and 3
+    return (unsigned)t;
+}
+// float -> unsigned with the same order
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ int2 lane_value(int2 v, int src) {      // src: the same in every lane
+    return make_int2(__builtin_amdgcn_readlane(v.x, src), __builtin_amdgcn_readlane(v.y, src));
+}
+
 // ---- binning ----
 // (a point outside the image raises counters[2] and is left out; the call then fails, but nothing is indexed with it)
-__global__ void cell_count_kernel(const int32_t *__restrict__ xy, int n, int rows, int cols, int shift, int gw, unsigned *__restrict__ cell_count, int *__restrict__ counters) {
+// counters[4..7]: the bounding box of the points (min x, min y, max x, max y; started at the opposite extremes by mesh_reset_kernel),
+// one set of atomics per block of 1024 threads (they all hit one cache line)
+__global__ __launch_bounds__(1024) void cell_count_kernel(const int32_t *__restrict__ xy, int n, int rows, int cols, int shift, int gw,
+                                                          unsigned *__restrict__ cell_count, int *__restrict__ counters) {
+    __shared__ int box[16][4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = xy[2 * i], y = xy[2 * i + 1];
-    if (x < 0 || x >= cols || y < 0 || y >= rows) { atomicOr(&counters[2], 1); return; }
-    atomicAdd(&cell_count[(y >> shift) * gw + (x >> shift)], 1u);
+    int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+    if (i < n) {
+        const int x = xy[2 * i], y = xy[2 * i + 1];
+        if (x < 0 || x >= cols || y < 0 || y >= rows) atomicOr(&counters[2], 1);
+        else {
+            atomicAdd(&cell_count[(y >> shift) * gw + (x >> shift)], 1u);
+            x0 = x1 = x; y0 = y1 = y;
+        }
+    }
+    x0 = (int)wave_min_u32((unsigned)x0); y0 = (int)wave_min_u32((unsigned)y0);
+    x1 = (int)~wave_min_u32(~(unsigned)(x1 + 1)) - 1; y1 = (int)~wave_min_u32(~(unsigned)(y1 + 1)) - 1;      // (maximum of values >= -1: the minimum of the complements of value + 1)
+    if ((threadIdx.x & 63) == 0) { int *b = box[threadIdx.x >> 6]; b[0] = x0; b[1] = y0; b[2] = x1; b[3] = y1; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x, waves = (blockDim.x + 63) >> 6;
+        int v = box[0][k];
+        for (int w = 1; w < waves; ++w) v = k < 2 ? min(v, box[w][k]) : max(v, box[w][k]);
+        if (k < 2) { if (v != 0x7fffffff) atomicMin(&counters[4 + k], v); }
+        else if (v >= 0) atomicMax(&counters[4 + k], v);
+    }
+}
+
+// What a triangulation starts from, in one launch: cell counts and fill counters, lead counts and counters zero, the bounding box
+// inside out, every slot of the binned list unfilled (index -1).
+__global__ void mesh_reset_kernel(unsigned *__restrict__ cells, int n_cell_words, int *__restrict__ lead_count, int n_lead, int2 *__restrict__ binned, int n,
+                                  int *__restrict__ counters) {
+    const int stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = t; i < n_cell_words; i += stride) cells[i] = 0u;
+    for (int i = t; i < n_lead; i += stride) lead_count[i] = 0;
+    for (int i = t; i < n; i += stride) binned[i] = make_int2(-1, -1);
+    if (t < 8) counters[t] = t == 4 || t == 5 ? 0x7fffffff : (t >= 6 ? -1 : 0);
 }
 
 __global__ void cell_fill_kernel(const int32_t *__restrict__ xy, int n, int rows, int cols, int shift, int gw, const unsigned *__restrict__ cell_start,
@@ -87,25 +152,22 @@ __global__ void cell_fill_kernel(const int32_t *__restrict__ xy, int n, int rows
     binned[slot] = make_int2(x | (y << 16), i);
 }
 
-// A repeated position is represented by its first index: the later copies get index -1 and take no part.
-__global__ void mark_repeats_kernel(int n, int shift, int gw, const unsigned *__restrict__ cell_start, int2 *__restrict__ binned, int *__restrict__ dead) {
+// A repeated position is represented by its first index: the later copies lose theirs (the top bit of the index is set, which
+// makes it negative) and take no part.  Copies are compared by their indices as first written (the top bit masked off), so
+// it does not matter which of them have been marked already.
+__global__ void mark_repeats_kernel(int n, int shift, int gw, const unsigned *__restrict__ cell_start, int2 *__restrict__ binned) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int2 me = binned[i];
-    if (me.y < 0) { dead[i] = 0; return; }                 // an unfilled slot (the call fails: a point outside the image)
+    if (me.x < 0) return;                                  // an unfilled slot (the call fails: a point outside the image)
+    const int my_id = me.y & 0x7fffffff;
     const int cell = ((int)((unsigned)me.x >> 16) >> shift) * gw + ((me.x & 0xffff) >> shift);
     bool repeat = false;
     for (unsigned j = cell_start[cell]; j < cell_start[cell + 1]; ++j) {
-        const int2 o = binned[j];
-        // compares against the indices as first written: dead[] is applied by the next kernel, not here
-        repeat = repeat || (o.x == me.x && o.y < me.y);
+        const int ox = binned[j].x, oy = __hip_atomic_load(&binned[j].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        repeat = repeat || (ox == me.x && (oy & 0x7fffffff) < my_id);
     }
-    dead[i] = repeat ? 1 : 0;
-}
-
-__global__ void apply_repeats_kernel(int n, int2 *__restrict__ binned, const int *__restrict__ dead) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && dead[i]) binned[i].y = -1;
+    if (repeat) atomicOr(&binned[i].y, (int)0x80000000);
 }
 
 // ---- the ring of one point ----
@@ -124,7 +186,12 @@ __global__ void apply_repeats_kernel(int n, int2 *__restrict__ binned, const int
 //         for 128 rows of cells at a time, every lane works out which columns of ITS two rows can hold a better
 //         candidate (inside the winner's circle, on the searched side of the line p a) and reads those rows' bounds,
 //         and the NW wavefronts share out the candidates of all rows in chunks of 64; their winners meet in LDS.
-constexpr int WIDE_CAP = 1024;
+constexpr int WIDE_CAP = 384;
+
+#ifdef SVX_MESH_PROBE        // measurement aid: what the second pass spends on each point {slot, ring steps, searches of all points, 10 ns ticks, held candidates}
+__device__ int mesh_probe[8192][6];
+__device__ int mesh_probe_n;
+#endif
 
 template <int NW, int MODE>
 __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restrict__ binned, int n, const unsigned *__restrict__ cell_start, int shift,
@@ -137,9 +204,14 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
     __shared__ int2 wide[MODE == 1 ? WIDE_CAP : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_todo = MODE == 0 ? n : counters[in_slot];
+    const int X0 = counters[4], Y0 = counters[5], X1 = counters[6], Y1 = counters[7];      // the points' bounding box
     const int2 none = make_int2(-1, -1);
     for (int w = blockIdx.x; w < n_todo; w += gridDim.x) {
         const int slot = MODE == 0 ? w : todo_in[w];
+#ifdef SVX_MESH_PROBE
+        const long long probe_t0 = wall_clock64();
+        int probe_steps = 0, probe_far = 0;
+#endif
         const int2 me = binned[slot];
         if (MODE == 0 && me.y < 0) continue;                 // a repeated position (or an unfilled slot)
         const DPt p = unpack(me);
@@ -147,29 +219,43 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
         const int cx = p.x >> shift, cy = p.y >> shift;
         // what the candidates guarantee: every point within `reach` pixels of p (no limit on a side where the window
         // ends at the image border; -1: no limit at all)
+        // The held window as a pixel box, and around it the box that holds every point (X0..X1, Y0..Y1: their bounding box,
+        // which the key points' borders keep well inside the frame).  A circle (or half-plane) that meets no part of that box
+        // outside the window can hold no point that is not among the held candidates: the four rectangles outside the window
+        // are tested one by one (this also passes the large circles of the flat triangles along the hull, which lie outside
+        // the points' box, and the hull edges along its sides, where many points lie on one line).
+        // mode 1: the window of half-width W, or the largest of W / 2, W / 4 whose points fit on chip (lane r looks at row r of the window)
+        int We = W, n_wide = 0, w_s = 0, w_cnt = 0, w_incl = 0;
+        if (MODE == 1) {
+            for (int attempt = 0;; ++attempt, We >>= 1) {
+                const int xa = max(cx - We, 0), xb = min(cx + We + 1, gw), ya = max(cy - We, 0), yb = min(cy + We + 1, gh);
+                w_s = 0; w_cnt = 0;
+                if (ya + lane < yb) { w_s = (int)cell_start[(ya + lane) * gw + xa]; w_cnt = (int)cell_start[(ya + lane) * gw + xb] - w_s; }
+                w_incl = (int)wave_scan_u32((unsigned)w_cnt);  // running total over the rows
+                n_wide = __builtin_amdgcn_readlane(w_incl, 63);
+                if (n_wide <= WIDE_CAP && yb - ya <= 64) break;
+                if (attempt == 2) { n_wide = -1; break; }     // still too many: nothing held on chip, nothing guaranteed
+            }
+        }
+        const int bx0 = max(cx - We, 0) << shift, bx1 = (min(cx + We + 1, gw) << shift) - 1;
+        const int by0 = max(cy - We, 0) << shift, by1 = (min(cy + We + 1, gh) << shift) - 1;
         int reach = 0x7fffffff;
-        if (cx - W > 0) reach = min(reach, p.x - ((cx - W) << shift));
-        if (cx + W + 1 < gw) reach = min(reach, ((cx + W + 1) << shift) - 1 - p.x);
-        if (cy - W > 0) reach = min(reach, p.y - ((cy - W) << shift));
-        if (cy + W + 1 < gh) reach = min(reach, ((cy + W + 1) << shift) - 1 - p.y);
+        if (bx0 > X0) reach = min(reach, p.x - bx0);
+        if (bx1 < X1) reach = min(reach, bx1 - p.x);
+        if (by0 > Y0) reach = min(reach, p.y - by0);
+        if (by1 < Y1) reach = min(reach, by1 - p.y);
         if (reach == 0x7fffffff) reach = -1;
-        // The held window as a pixel box, and the frame around it.  A circle (or half-plane) that meets no part of the frame
-        // outside the box can hold no point that is not among the held candidates: the four rectangles of the frame outside
-        // the box are tested one by one (this also passes the large circles of the flat triangles along the hull, most of
-        // which lie outside the frame).
-        const int bx0 = max(cx - W, 0) << shift, bx1 = (min(cx + W + 1, gw) << shift) - 1;
-        const int by0 = max(cy - W, 0) << shift, by1 = (min(cy + W + 1, gh) << shift) - 1;
-        const int X1 = (gw << shift) - 1, Y1 = (gh << shift) - 1;
         auto circle_in_box = [&](const Circle &c) -> bool {
             if (reach < 0) return true;
             if (reach == 0) return false;                     // (mode 1 with nothing held)
+            if (4.0 * c.r2 <= (double)reach * (double)reach) return true;      // p lies on the circle: no point of it is further from p than the diameter
             const double mx = (double)p.x + c.ox, my = (double)p.y + c.oy;
             auto clear = [&](int x0, int y0, int x1, int y1) {
                 if (x0 > x1 || y0 > y1) return true;
                 const double dx = fmax(fmax((double)x0 - mx, mx - (double)x1), 0.0), dy = fmax(fmax((double)y0 - my, my - (double)y1), 0.0);
                 return dx * dx + dy * dy > c.r2 + 1e-6;
             };
-            return clear(0, 0, bx0 - 1, Y1) && clear(bx1 + 1, 0, X1, Y1) && clear(bx0, 0, bx1, by0 - 1) && clear(bx0, by1 + 1, bx1, Y1);
+            return clear(X0, Y0, bx0 - 1, Y1) && clear(bx1 + 1, Y0, X1, Y1) && clear(max(bx0, X0), Y0, min(bx1, X1), by0 - 1) && clear(max(bx0, X0), by1 + 1, min(bx1, X1), Y1);
         };
         // the 7 x 7 cells around the point into registers (mode 0): the row bounds are read by independent loads
         int2 c0 = none, c1 = none;
@@ -196,40 +282,38 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
             if (j1 >= 0) c1 = binned[j1];
             overfull = n_near > 128;
         }
-        // the window of half-width W into LDS (mode 1): lane r reads the bounds of row r of the window (every wavefront, the same)
-        int n_wide = 0;
+        // the window's points into LDS (mode 1), row by row
         if (MODE == 1) {
-            const int xa = max(cx - W, 0), xb = min(cx + W + 1, gw), ya = max(cy - W, 0), yb = min(cy + W + 1, gh);
-            int s = 0, cnt = 0;
-            if (ya + lane < yb) { s = (int)cell_start[(ya + lane) * gw + xa]; cnt = (int)cell_start[(ya + lane) * gw + xb] - s; }
-            int incl = cnt;                                   // running total over the rows
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += t;
-            }
-            n_wide = __shfl(incl, 63, 64);
             __syncthreads();                                  // the last point's reads of the LDS window are done
-            if (n_wide > WIDE_CAP || yb - ya > 64) { n_wide = 0; reach = 0; }      // too many: nothing held on chip, nothing guaranteed
-            else
-                for (int r = 0; r < yb - ya; ++r) {
-                    const int rs = __shfl(s, r, 64), rc = __shfl(cnt, r, 64), at = __shfl(incl - cnt, r, 64);
+            if (n_wide < 0) { n_wide = 0; reach = 0; }
+            else {
+                const int n_rows = min(cy + We + 1, gh) - max(cy - We, 0);
+                for (int r = 0; r < n_rows; ++r) {
+                    const int rs = __shfl(w_s, r, 64), rc = __shfl(w_cnt, r, 64), at = __shfl(w_incl - w_cnt, r, 64);
                     for (int i = threadIdx.x; i < rc; i += 64 * NW) wide[at + i] = binned[rs + i];
                 }
+            }
             __syncthreads();
         }
-        // near(f): f(candidate or none) for every lane of every chunk of the candidates held on chip
-        auto near = [&](auto f) {
-            if (MODE == 1) {
-                for (int base = 0; base < n_wide; base += 64) f(base + lane < n_wide ? wide[base + lane] : none);
-                return;
-            }
-            f(c0);
-            if (n_near > 64) f(c1);
-        };
+        // the candidates held on chip, in registers: lane l holds candidates l, l + 64, ... (n_chunks registers in use)
+        constexpr int NC = MODE == 0 ? 2 : WIDE_CAP / 64;
+        int2 cand[NC];
+        int n_chunks;
+        if (MODE == 0) { cand[0] = c0; cand[1] = c1; n_chunks = n_near > 64 ? 2 : 1; }
+        else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) cand[j] = 64 * j + lane < n_wide ? wide[64 * j + lane] : none;
+            n_chunks = (n_wide + 63) >> 6;
+        }
         // far(f, cols): mode 1 only, f(candidate or none) for every lane of every chunk this wavefront takes of the binned
         // list; cols(y0, y1, x0, x1) narrows the pixel columns [x0, x1] worth reading in the pixel rows y0..y1 (x0 > x1: none)
+        // (a lane per row of cells that walks its own row is faster when a search meets a handful of points and twice as slow
+        // when it meets hundreds, which is what the slowest points do)
         auto far = [&](auto f, auto cols) {
             if (MODE != 1) return;
+#ifdef SVX_MESH_PROBE
+            ++probe_far;
+#endif
             for (int g = 0; g < gh; g += 128) {                // 128 rows of cells a round: two per lane, their loads in flight together
                 int s[2] = {0, 0}, cnt[2] = {0, 0};
 #pragma unroll
@@ -245,15 +329,12 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                         }
                     }
                 }
-                int incl0 = cnt[0], incl1 = cnt[1];
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t0 = __shfl_up(incl0, o, 64), t1 = __shfl_up(incl1, o, 64);
-                    if (lane >= o) { incl0 += t0; incl1 += t1; }
-                }
-                const int total0 = __shfl(incl0, 63, 64), total = total0 + __shfl(incl1, 63, 64);
+                const int incl0 = (int)wave_scan_u32((unsigned)cnt[0]), incl1 = (int)wave_scan_u32((unsigned)cnt[1]);
+                const int total0 = __builtin_amdgcn_readlane(incl0, 63), total = total0 + __builtin_amdgcn_readlane(incl1, 63);
                 const int at0 = incl0 - cnt[0], at1 = total0 + incl1 - cnt[1];          // where each row starts among the round's candidates
                 for (int base = 64 * wave; base < total; base += 256 * NW) {          // four loads in flight
                     int2 c[4];
+#pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int idx = base + 64 * NW * u + lane;
                         c[u] = none;
@@ -269,6 +350,7 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                             if (idx < total) c[u] = binned[(second ? rs1 : rs0) + idx - (second ? ra1 : ra0)];
                         }
                     }
+#pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (base + 64 * NW * u < total) f(c[u]);
                 }
@@ -289,8 +371,15 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
             const int dx = (c.x & 0xffff) - p.x, dy = (int)((unsigned)c.x >> 16) - p.y;
             nearer(dx * dx + dy * dy, c);
         };
-        near(by_distance);
-        for (int o = 32; o; o >>= 1) nearer(__shfl_xor(bd, o, 64), make_int2(__shfl_xor(bc.x, o, 64), __shfl_xor(bc.y, o, 64)));
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (j < n_chunks) by_distance(cand[j]);
+        {   // (which of several nearest points is taken does not matter: each of them is a neighbour)
+            const unsigned dmin = wave_min_u32((unsigned)bd);
+            const unsigned long long who = __ballot((unsigned)bd == dmin);
+            bc = dmin == 0x7fffffffu ? none : lane_value(bc, __ffsll((long long)who) - 1);
+            bd = (int)dmin;
+        }
         if (MODE == 1 && !(bc.y >= 0 && (reach < 0 || (long long)bd <= (long long)reach * reach))) {
             const double r_near = bd == 0x7fffffff ? 1e30 : sqrt((double)bd) + 1.0;     // a nearer point lies within the nearest found in the window
             far(by_distance, [&](double y0, double y1, double &x0, double &x1) { disc_cols((double)p.x, (double)p.y, r_near, y0, y1, x0, x1); });
@@ -316,6 +405,9 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                 int axy = a0c.x;
                 for (int step = 0;; ++step) {
                     if (step >= MAX_RING) { verdict = -2; break; }
+#ifdef SVX_MESH_PROBE
+                    ++probe_steps;
+#endif
                     DPt b; int2 bcc = none;
                     Circle circ;
                     // the nearby candidates ranked in double; when none of them lies on the searched side (mode 2), all that do
@@ -343,8 +435,22 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                             if (ok < bk || (ok == bk && oy > bkc.y)) { bk = ok; bkc = make_int2(ox, oy); }
                         }
                     };
-                    near(rank);
-                    rank_meet();
+                    {   // the held candidates in single precision (what the order of the rounded quotients leaves open, the exact pass settles)
+                        float kb = __builtin_inff();
+                        int2 kc = none;
+#pragma unroll
+                        for (int j = 0; j < NC; ++j)
+                            if (j < n_chunks) {
+                                const int2 cc = cand[j];
+                                const int ccx = (cc.x & 0xffff) - p.x, ccy = (int)((unsigned)cc.x >> 16) - p.y;
+                                const int cr = __mul24(ax, ccy) - __mul24(ay, ccx);
+                                const bool on = cc.y >= 0 && cc.x != me.x && cc.x != axy && (dir == 0 ? cr > 0 : cr < 0);
+                                const float k = (float)(__mul24(ccx, ccx) + __mul24(ccy, ccy) - (__mul24(ax, ccx) + __mul24(ay, ccy))) * __builtin_amdgcn_rcpf((float)abs(cr));
+                                if (on && k < kb) { kb = k; kc = cc; }
+                            }
+                        const unsigned key = ordered_bits(kb), kmin = wave_min_u32(key);
+                        if (kmin != ordered_bits(__builtin_inff())) bkc = lane_value(kc, __ffsll((long long)__ballot(key == kmin)) - 1);
+                    }
                     // No held candidate on the searched side: p -> a is a hull edge if no point outside the held window lies there
                     // either, which is certain when the part of the frame outside the window's box (up to four rectangles) lies
                     // wholly on the other side of the line: a rectangle does when its four corners do.
@@ -354,17 +460,31 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                         auto clear = [&](int x0, int y0, int x1, int y1) {
                             return x0 > x1 || y0 > y1 || (away(x0, y0) && away(x1, y0) && away(x0, y1) && away(x1, y1));
                         };
-                        side_empty = clear(0, 0, bx0 - 1, Y1) && clear(bx1 + 1, 0, X1, Y1) && clear(bx0, 0, bx1, by0 - 1) && clear(bx0, by1 + 1, bx1, Y1);
+                        side_empty = clear(X0, Y0, bx0 - 1, Y1) && clear(bx1 + 1, Y0, X1, Y1) && clear(max(bx0, X0), Y0, min(bx1, X1), by0 - 1) && clear(max(bx0, X0), by1 + 1, min(bx1, X1), Y1);
                     }
+                    // No held candidate on the searched side, and points may lie there: a first winner is looked for in growing
+                    // boxes of cells around p (ranking the whole half-plane would read half of all points to tell what the nearest
+                    // ones tell as well); the exact pass below then only reads what lies inside that winner's circle.
+                    bool all_ranked = false;                              // every point on the searched side has been ranked
                     if (MODE == 1 && bkc.y < 0 && !side_empty) {
-                        far(rank, side_cols);
-                        rank_meet();
-                        if (NW > 1) {
-                            __syncthreads();
-                            if (lane == 0) { win[wave] = bkc; win_k[wave] = bk; }
-                            __syncthreads();
-                            for (int v = 0; v < NW; ++v)
-                                if (win_k[v] < bk || (win_k[v] == bk && win[v].y > bkc.y)) { bk = win_k[v]; bkc = win[v]; }
+                        for (int wk = 4 * max(W, 1);; wk *= 4) {
+                            const bool all = cx - wk <= 0 && cx + wk + 1 >= gw && cy - wk <= 0 && cy + wk + 1 >= gh;
+                            const double fx0 = (double)(max(cx - wk, 0) << shift), fx1 = (double)((min(cx + wk + 1, gw) << shift) - 1);
+                            const double fy0 = (double)(max(cy - wk, 0) << shift), fy1 = (double)((min(cy + wk + 1, gh) << shift) - 1);
+                            far(rank, [&](double y0, double y1, double &x0, double &x1) {
+                                if (y1 < fy0 || y0 > fy1) { x0 = 1.0; x1 = 0.0; return; }
+                                side_cols(y0, y1, x0, x1);
+                                x0 = fmax(x0, fx0); x1 = fmin(x1, fx1);
+                            });
+                            rank_meet();
+                            if (NW > 1) {
+                                __syncthreads();
+                                if (lane == 0) { win[wave] = bkc; win_k[wave] = bk; }
+                                __syncthreads();
+                                for (int v = 0; v < NW; ++v)
+                                    if (win_k[v] < bk || (win_k[v] == bk && win[v].y > bkc.y)) { bk = win_k[v]; bkc = win[v]; }
+                            }
+                            if (bkc.y >= 0 || all) { all_ranked = all; break; }
                         }
                     }
                     if (bkc.y >= 0) { bcc = bkc; b = unpack(bcc); circ.set(p, a, b); }
@@ -386,8 +506,19 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                             circ.set(p, a, b);
                         }
                     };
-                    near(hands);
-                    if (MODE == 1 && !side_empty && !(bcc.y >= 0 && circle_in_box(circ))) {
+                    for (;;) {                                            // the held candidates: every lane asks its own until one beats the winner
+                        bool up = false;
+                        int2 mine = none;
+#pragma unroll
+                        for (int j = 0; j < NC; ++j)
+                            if (j < n_chunks && !up && beats(cand[j])) { up = true; mine = cand[j]; }
+                        const unsigned long long who = __ballot(up);
+                        if (!who) break;
+                        bcc = lane_value(mine, __ffsll((long long)who) - 1);
+                        b = unpack(bcc);
+                        circ.set(p, a, b);
+                    }
+                    if (MODE == 1 && !side_empty && !(all_ranked && bkc.y < 0) && !(bcc.y >= 0 && circle_in_box(circ))) {
                         // the searched side of the line p -> a and, if there is a winner, its circle
                         const bool has = bcc.y >= 0;
                         const double mx = (double)p.x + circ.ox, my = (double)p.y + circ.oy, mr = has ? sqrt(circ.r2) : 0.0;
@@ -422,6 +553,12 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                 }
             }
         }
+#ifdef SVX_MESH_PROBE
+        if (MODE == 1 && threadIdx.x == 0) {
+            const int k = atomicAdd(&mesh_probe_n, 1);
+            if (k < 8192) { mesh_probe[k][0] = slot; mesh_probe[k][1] = probe_steps; mesh_probe[k][2] = probe_far; mesh_probe[k][3] = (int)(wall_clock64() - probe_t0); mesh_probe[k][4] = n_wide; mesh_probe[k][5] = me.x; }
+        }
+#endif
         if (threadIdx.x == 0) {
             if (verdict == 0) lead_count[p.id] = n_lead;
             else if (verdict == -1 && todo_out) todo_out[atomicAdd(&counters[out_slot], 1)] = slot;
@@ -433,8 +570,14 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
 
 // Triangles in their final order: point by point, a point's triangles by their other two indices.
 __global__ void write_triangles_kernel(const int32_t *__restrict__ xy, int n, const int2 *__restrict__ lead_all, const int *__restrict__ lead_count,
-                                       const unsigned *__restrict__ lead_start, int capacity, int32_t *__restrict__ tri_idx, int32_t *__restrict__ tri_xy) {
+                                       const unsigned *__restrict__ lead_start, int capacity, int32_t *__restrict__ tri_idx, int32_t *__restrict__ tri_xy,
+                                       const int *__restrict__ counters, svx_mail *mail, unsigned seq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && mail) {                                  // the host sizes the next launches by the number of triangles
+        mail->v[0] = lead_start[n];
+        mail->v[1] = (unsigned)counters[0]; mail->v[2] = (unsigned)counters[1]; mail->v[3] = (unsigned)counters[2];
+        svx_mail_post(mail, seq);
+    }
     if (i >= n) return;
     const int cnt = lead_count[i];
     const int2 *mine = lead_all + (size_t)i * MAX_LEAD;
@@ -485,8 +628,8 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
     {
         char *at = nullptr;
         carve<int32_t>(at, 6 * max_tri); carve<int32_t>(at, 3 * max_tri); carve<float>(at, 3 * max_tri);
-        carve<unsigned>(at, 2 * (size_t)n_cells + 2); carve<int2>(at, n); carve<int>(at, n); carve<int>(at, n);
-        carve<unsigned>(at, (size_t)n + 1); carve<int>(at, (size_t)n + 1); carve<int2>(at, (size_t)n * MAX_LEAD); carve<int>(at, 4);
+        carve<unsigned>(at, 2 * (size_t)n_cells + 2); carve<int2>(at, n); carve<int>(at, n);
+        carve<unsigned>(at, (size_t)n + 1); carve<int>(at, (size_t)n + 1); carve<int2>(at, (size_t)n * MAX_LEAD); carve<int>(at, 8);
         bytes = (size_t)(at - (char *)nullptr);
     }
     int rc = svx_block_reserve(ctx, &ctx->tri, &ctx->tri_bytes, bytes, "mesh on the device");
@@ -498,42 +641,41 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
     unsigned *cell_start = carve<unsigned>(at, 2 * (size_t)n_cells + 2);   // counts, scanned in place; then the fill counters
     unsigned *cell_fill = cell_start + n_cells + 1;
     int2 *binned = carve<int2>(at, n);
-    int *dead = carve<int>(at, n);
     int *todo = carve<int>(at, n);
     unsigned *lead_start = carve<unsigned>(at, (size_t)n + 1);
     int *lead_count = carve<int>(at, (size_t)n + 1);
     int2 *lead_all = carve<int2>(at, (size_t)n * MAX_LEAD);
-    int *counters = carve<int>(at, 4);        // [0] points left by the first pass, [1] limits exceeded, [2] point outside the image, [3] unused
+    int *counters = carve<int>(at, 8);        // [0] points left by the first pass, [1] limits exceeded, [2] point outside the image, [3] unused, [4..7] the points' bounding box
     hipStream_t st = ctx->stream;
     const unsigned nb = svx_cdiv(n, 256);
-    SVX_HIP(ctx, hipMemsetAsync(cell_start, 0, (2 * (size_t)n_cells + 2) * sizeof(unsigned), st));
-    SVX_HIP(ctx, hipMemsetAsync(lead_count, 0, ((size_t)n + 1) * sizeof(int), st));
-    SVX_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
-    SVX_HIP(ctx, hipMemsetAsync(binned, 0xff, (size_t)n * sizeof(int2), st));
+    mesh_reset_kernel<<<std::min(svx_cdiv(std::max(2 * n_cells + 2, n + 1), 256), 1024u), 256, 0, st>>>(cell_start, 2 * n_cells + 2, lead_count, n + 1, binned, n, counters);
+    SVX_LAUNCH_CHECK(ctx, "mesh_reset_kernel");
     int h_counters[4];
-    cell_count_kernel<<<nb, 256, 0, st>>>(pts_xy, n, rows, cols, shift, gw, cell_start, counters);
+    cell_count_kernel<<<svx_cdiv(n, 1024), 1024, 0, st>>>(pts_xy, n, rows, cols, shift, gw, cell_start, counters);
     SVX_LAUNCH_CHECK(ctx, "cell_count_kernel");
-    scan4_kernel<<<1, 1024, 0, st>>>(cell_start, n_cells);
+    scan4_kernel<<<1, 1024, 0, st>>>(cell_start, n_cells, cell_start, nullptr, 0);
     SVX_LAUNCH_CHECK(ctx, "scan4_kernel");
     cell_fill_kernel<<<nb, 256, 0, st>>>(pts_xy, n, rows, cols, shift, gw, cell_start, cell_fill, binned);
     SVX_LAUNCH_CHECK(ctx, "cell_fill_kernel");
-    mark_repeats_kernel<<<nb, 256, 0, st>>>(n, shift, gw, cell_start, binned, dead);
+    mark_repeats_kernel<<<nb, 256, 0, st>>>(n, shift, gw, cell_start, binned);
     SVX_LAUNCH_CHECK(ctx, "mark_repeats_kernel");
-    apply_repeats_kernel<<<nb, 256, 0, st>>>(n, binned, dead);
-    SVX_LAUNCH_CHECK(ctx, "apply_repeats_kernel");
     ring_wave_kernel<1, 0><<<std::min(n, 65536), 64, 0, st>>>(binned, n, cell_start, shift, gw, gh, W1, nullptr, 0, lead_all, lead_count, todo, counters, 0);
     SVX_LAUNCH_CHECK(ctx, "ring_wave_kernel");
     ring_wave_kernel<2, 1><<<std::min(n, 8192), 128, 0, st>>>(binned, n, cell_start, shift, gw, gh, W2, todo, 0, lead_all, lead_count, nullptr, counters, 3);
     SVX_LAUNCH_CHECK(ctx, "ring_wave_kernel");
-    SVX_HIP(ctx, hipMemcpyAsync(lead_start, lead_count, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
-    scan4_kernel<<<1, 1024, 0, st>>>(lead_start, n);
+    svx_mail *mail = nullptr;
+    unsigned seq = 0;
+    rc = svx_mail_next(ctx, &mail, &seq);
+    if (rc) return rc;
+    scan4_kernel<<<1, 1024, 0, st>>>(lead_start, n, (const unsigned *)lead_count, nullptr, 0);
     SVX_LAUNCH_CHECK(ctx, "scan4_kernel");
-    write_triangles_kernel<<<nb, 256, 0, st>>>(pts_xy, n, lead_all, lead_count, lead_start, (int)max_tri, tri_idx, tri_xy);
+    write_triangles_kernel<<<nb, 256, 0, st>>>(pts_xy, n, lead_all, lead_count, lead_start, (int)max_tri, tri_idx, tri_xy, counters, mail, seq);
     SVX_LAUNCH_CHECK(ctx, "write_triangles_kernel");
-    unsigned total = 0;
-    SVX_HIP(ctx, hipMemcpyAsync(&total, lead_start + n, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    SVX_HIP(ctx, hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, st));
-    SVX_HIP(ctx, hipStreamSynchronize(st));
+    const unsigned *got = nullptr;                        // the number of triangles, then counters[0..2], as soon as they are known
+    rc = svx_mail_wait(ctx, seq, &got);
+    if (rc) return rc;
+    const unsigned total = got[0];
+    for (int k = 0; k < 3; ++k) h_counters[k] = (int)got[1 + k];
     if (h_counters[2]) return svx_fail(ctx, SVX_ERR_INVALID_ARG, "mesh on the device: support point outside the image");
     if (h_counters[1] || total > max_tri) return SVX_ERR_UNSUPPORTED;
     ctx->mesh_left_over = 0;
@@ -544,6 +686,20 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
     *abc_out = abc;
     return SVX_OK;
 }
+
+#ifdef SVX_MESH_PROBE
+// copies the probe records of the second pass to the host and clears them; returns their number
+SVX_API int svx_mesh_probe_dump(int *out, int capacity) {
+    int n = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(mesh_probe_n), sizeof(int));
+    n = std::min(std::min(n, capacity), 8192);
+    if (n) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mesh_probe), (size_t)n * 6 * sizeof(int));
+    const int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mesh_probe_n), &zero, sizeof(int));
+    return n;
+}
+#endif
 
 SVX_API int svx_mesh_device_stats(const svx_ctx *ctx, int *left_by_first_pass, int *left_by_second_pass) {
     if (!ctx) return SVX_ERR_INVALID_ARG;

@@ -84,9 +84,17 @@ __global__ void resample_emit_kernel(const int32_t *__restrict__ xy, int n_slots
     owner[(long)y * cols + x] = 0x7fffffff;          // free again for the next step
 }
 
-__global__ void fill_int_kernel(int *__restrict__ v, long n, int value) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = value;
+// Up to four fills in one launch: range k is words[k] 32-bit words of value[k] at p[k] (16-byte aligned; 0 words: none).
+struct FillRanges { uint32_t *p[4]; long words[4]; uint32_t value[4]; };
+__global__ __launch_bounds__(256) void fill_ranges_kernel(FillRanges r) {
+    const long stride = (long)gridDim.x * blockDim.x, t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 v4 = make_uint4(r.value[k], r.value[k], r.value[k], r.value[k]);
+        const long quads = r.words[k] >> 2;
+        for (long i = t; i < quads; i += stride) reinterpret_cast<uint4 *>(r.p[k])[i] = v4;
+        for (long i = 4 * quads + t; i < r.words[k]; i += stride) r.p[k][i] = r.value[k];
+    }
 }
 
 // Bump allocator over one device allocation (the context's workspace belongs to the entry points called below).
@@ -205,6 +213,16 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     int off[2] = {0, 0};
     SVX_TRY(svx_high_gradient_points(ctx, grad, R, Cc, 1, prm->gradThreshold, pts, (int)n, off));
     const int n_hg = off[1];
+    // the high-gradient points are most of what goes back to the host (.cpp:624-637): their copy starts now, beside the frame's kernels
+    const int take_hg = std::min(n_hg, capacity);
+    int32_t *stage = nullptr;
+    {
+        void *pin = nullptr;
+        const size_t room = (size_t)std::min((long)capacity, (long)n_hg + (long)n) * 8;
+        if (room) SVX_TRY(svx_side_reserve(ctx, room, &pin));
+        stage = (int32_t *)pin;
+        if (take_hg) SVX_TRY(svx_side_copy_to_host(ctx, stage, pts, (size_t)take_hg * 8));
+    }
     // .cpp:289-292: the blur kernel size is `(int)applyBlur` = 1 (.cpp:207), i.e. the blur is the identity
 
     clk.mark(1);
@@ -233,16 +251,27 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
 
     clk.mark(4);
     // support points of the mesh, in insertion order, repeated positions dropped (.cpp:434-445): a ranked write on the device
-    SVX_HIP(ctx, hipMemsetAsync(disparities, 0, n * sizeof(float), ctx->stream));
-    SVX_HIP(ctx, hipMemsetAsync(taken, 0, n, ctx->stream));
+    {   // what the frame starts from, in one launch: prior and claimed pixels zero, final costs 25 (.cpp:448), no pixel owned by a resampling slot
+        FillRanges fr = {};
+        fr.p[0] = (uint32_t *)disparities; fr.words[0] = (long)n; fr.value[0] = 0u;
+        fr.p[1] = (uint32_t *)taken; fr.words[1] = (long)(n / 4); fr.value[1] = 0u;
+        fr.p[2] = (uint32_t *)final_costs; fr.words[2] = (long)(n / 4); fr.value[2] = 0x19191919u;
+        fr.p[3] = (uint32_t *)owner; fr.words[3] = prm->nIters > 1 ? (long)n : 0; fr.value[3] = 0x7fffffffu;
+        fill_ranges_kernel<<<std::min(svx_cdiv((long)n / 4, 256), 2048u), 256, 0, ctx->stream>>>(fr);
+        SVX_LAUNCH_CHECK(ctx, "fill_ranges_kernel");
+    }
     int n_sup = 0;
     auto read_total = [&](int n_flags, int *total) -> int {       // scans rank[0 .. n_flags) in place and brings the total to the host
-        scan4_kernel<<<1, 1024, 0, ctx->stream>>>(rank, n_flags);
+        svx_mail *mail = nullptr;
+        unsigned seq = 0;
+        int r = svx_mail_next(ctx, &mail, &seq);
+        if (r) return r;
+        scan4_kernel<<<1, 1024, 0, ctx->stream>>>(rank, n_flags, rank, mail, seq);
         SVX_LAUNCH_CHECK(ctx, "scan4_kernel");
-        unsigned t = 0;
-        SVX_HIP(ctx, hipMemcpyAsync(&t, rank + n_flags, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        *total = (int)t;
+        const unsigned *got = nullptr;
+        r = svx_mail_wait(ctx, seq, &got);
+        if (r) return r;
+        *total = (int)got[0];
         return SVX_OK;
     };
     if (nl && nr) {
@@ -253,9 +282,8 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
         SVX_LAUNCH_CHECK(ctx, "support_emit_kernel");
     }
 
-    // final maps: the caller's disparity map (input-sized, .cpp:190) restricted to the cropped frame; costs start at 25 (.cpp:448)
+    // final maps: the caller's disparity map (input-sized, .cpp:190) restricted to the cropped frame (the costs were started above)
     SVX_HIP(ctx, hipMemcpy2DAsync(final_disp, (size_t)Cc * 4, disparity_map, (size_t)cols * 4, (size_t)Cc * 4, R, hipMemcpyDeviceToDevice, ctx->stream));
-    SVX_HIP(ctx, hipMemsetAsync(final_costs, 25, n, ctx->stream));
 
     clk.mark(5);
     // By default the triangulation runs on the device, from the whole list each time (the mesh is a function of the point
@@ -270,10 +298,6 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     const bool mesh_on_device = svx_opt(ctx, SVX_OPT_MESH_ON_DEVICE) != 0 && R <= 8192 && Cc <= 8192;
     if (!mesh_on_device && prm->recordFullDisp && prm->nIters > 0 && svx_mesh_create(&mesh.m) != SVX_OK)
         return svx_fail(ctx, SVX_ERR_NOMEM, "svx_high_perf_stereo: mesh");
-    if (prm->nIters > 1) {
-        fill_int_kernel<<<svx_cdiv((long)n, 256), 256, 0, ctx->stream>>>(owner, (long)n, 0x7fffffff);
-        SVX_LAUNCH_CHECK(ctx, "fill_int_kernel");
-    }
     for (int iter = 1; iter <= prm->nIters; ++iter) {                                                   // .cpp:451
         // plane table and interpolation of the prior over the whole frame (.cpp:454-466, :532-554)
         if (prm->recordFullDisp) {
@@ -329,15 +353,12 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
 
     // computed points: the high-gradient set in raster order, then the mesh vertices
     *n_points = n_hg + n_sup;
-    const int take_hg = std::min(n_hg, capacity), take_sup = std::max(0, std::min(n_sup, capacity - n_hg));
-    // through the context's pinned staging buffer (one DMA each, then a host copy): a transfer straight into the caller's
-    // pageable memory is staged by the runtime in small pieces and takes three times as long for the 2.5 MB of a KITTI frame
-    void *pin = nullptr;
-    if (take_hg + take_sup) SVX_TRY(svx_pinned_reserve(ctx, (size_t)(take_hg + take_sup) * 8, &pin));
-    int32_t *stage = (int32_t *)pin;
-    if (take_hg) SVX_HIP(ctx, hipMemcpyAsync(stage, pts, (size_t)take_hg * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const int take_sup = std::max(0, std::min(n_sup, capacity - n_hg));
+    // the mesh vertices follow the high-gradient points in the same pinned block (a transfer straight into the caller's pageable
+    // memory is staged by the runtime in small pieces and takes three times as long)
     if (take_sup) SVX_HIP(ctx, hipMemcpyAsync(stage + 2 * (size_t)take_hg, sup_dev, (size_t)take_sup * 8, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SVX_TRY(svx_side_wait(ctx));
     if (take_hg) memcpy(points_xy_host, stage, (size_t)take_hg * 8);
     if (take_sup) memcpy(points_xy_host + 2 * (size_t)n_hg, stage + 2 * (size_t)take_hg, (size_t)take_sup * 8);
     clk.mark(9);

@@ -5,8 +5,8 @@ mkdir -p gpurun_out/${OUT:-r3a}
 rm -rf gpurun_out/${OUT:-r3a}/prof_mesh
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${OUT:-r3a}/prof_mesh -- python3 tools/time_mesh.py > gpurun_out/${OUT:-r3a}/prof_mesh.log 2>&1 || { tail -5 gpurun_out/${OUT:-r3a}/prof_mesh.log; exit 1; }
 python3 - <<'PY'
-import csv, glob
-rows = list(csv.DictReader(open(glob.glob("gpurun_out/${OUT:-r3a}/prof_mesh/*/*kernel_trace.csv")[0])))
+import csv, glob, os
+rows = list(csv.DictReader(open(glob.glob("gpurun_out/%s/prof_mesh/*/*kernel_trace.csv" % os.environ.get("OUT", "r3a"))[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:26] for r in rows]
 calls = [k for k, n in enumerate(names) if n.startswith("cell_count")]
