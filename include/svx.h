@@ -11,7 +11,9 @@
  *   - pointers are DEVICE pointers unless the parameter name ends in _host;
  *   - work is enqueued on the context's stream and is asynchronous with
  *     respect to the host unless the entry point has _host parameters (those
- *     return after their results are on the host);
+ *     return after their _host results are on the host; what the same call
+ *     leaves in device memory is still ordered by the stream only: read it on
+ *     that stream, or after svx_synchronize);
  *   - return value: SVX_OK (0) or a negative svx_status; svx_last_error()
  *     holds a message for the most recent failure of that context;
  *   - a context belongs to one device and one host thread at a time; distinct
@@ -344,7 +346,7 @@ int svx_exfast_detect(svx_ctx *ctx, const uint8_t *img, int rows, int cols, int 
  *   (.cpp:532-554) in one call: host support points, device disparities, device prior. */
 int svx_delaunay(svx_ctx *ctx, const int32_t *pts_xy_host, int n_pts, int32_t *tri_idx_host, int capacity, int *n_tri);
 /* The same triangulation computed on the device (device points in, device index triples out, in svx_delaunay's
- * order; *n_tri_host on the host, the call synchronises): every point finds the triangles around it from the points
+ * order; *n_tri_host is on the host when the call returns, the triples follow in stream order): every point finds the triangles around it from the points
  * near it, and the points that cannot be sure (next to large empty areas, on the hull) from all points.  Points
  * must lie inside a rows x cols frame of at most 8192 x 8192.  SVX_ERR_UNSUPPORTED for a point set with more than 256
  * triangles around one point (or 32 led by one point): svx_delaunay takes those.

@@ -10,12 +10,13 @@
 //   * walking a -> b until a0 comes back gives all triangles around p; when a side has no point (p is on the hull) the
 //     walk is finished clockwise from a0.
 // Candidates: the points are binned into square cells of about one point each (4 to 64 pixels a side); a point first
-// looks at the 7 x 7 cells around its own, which hold every point within three cells of it (more towards the image
-// border, where nothing lies outside).  A triangle found among them is the true one when its circumcircle lies within
-// that range (p is on the circle, so twice the radius bounds how far the circle reaches from p), and a point whose
-// triangles all pass owns its true ring.  Points that fail (next to empty areas, on the hull) look again at 21 x 21
-// cells, and what still fails is done by a workgroup each against ALL points.  A triangle is reported by its vertex of
-// smallest index, rotated to lead with it, and the list is ordered by (v0, v1, v2): the form svx_delaunay returns.
+// looks at the 7 x 7 cells around its own, which hold every point within three cells of it (more towards the sides of the
+// points' bounding box, outside which nothing lies).  A triangle found among them is the true one when its circumcircle
+// lies within that range (p is on the circle, so twice the radius bounds how far the circle reaches from p), and a point
+// whose triangles all pass owns its true ring.  Points that fail (next to empty areas, on the hull) look again at 17 x 17
+// cells, and where that does not settle a triangle either, at the points of ALL cells the triangle's circle meets.  A
+// triangle is reported by its vertex of smallest index, rotated to lead with it, and the list is ordered by (v0, v1, v2):
+// the form svx_delaunay returns.
 #include "svx_common.hpp"
 #include "svx_compact.hpp"
 #include <algorithm>
@@ -173,19 +174,21 @@ __global__ void mark_repeats_kernel(int n, int shift, int gw, const unsigned *__
 // ---- the ring of one point ----
 // A point is served by NW wavefronts whose lanes all hold the SAME winner so far.  For an edge (p, a) the candidates on the
 // searched side are ordered by where the centre of their circle through p and a lies on the bisector of p a, which is the
-// order of the quotient (|c|^2 - a.c) / |a x c| (coordinates relative to p): the nearby candidates are ranked by it in
-// double and the smallest becomes the winner.  Then every candidate is asked, 64 at a time, whether it beats the winner
-// under the exact test: a lane whose candidate does raises its hand, the first such candidate becomes the winner of all
-// lanes and the chunk is asked again, until no hand goes up.  The exact test runs in every lane at once or not at all,
-// and behind the enlarged-circle test it is rare; after the ranking it only settles ties and rounding.
+// order of the quotient (|c|^2 - a.c) / |a x c| (coordinates relative to p).  The candidates held on chip sit in registers,
+// lane l holding candidates l, l + 64, ...: every lane ranks its own by that quotient in single precision, the smallest of
+// the wavefront (a DPP minimum of the ordered bit patterns) becomes the winner, and then every lane asks its candidates
+// whether one beats the winner under the exact test: a lane whose candidate does raises its hand, the first such candidate
+// becomes the winner of all lanes and the lanes ask again, until no hand goes up.  The exact test runs behind a test against
+// the winner's circle, a little enlarged, in double, so it is rare; after the ranking it only settles ties and rounding.
 // MODE 0, the first pass: a wavefront per point of the binned list; the points of the 7 x 7 cells around it are gathered
 //         once into two registers per lane (more than 128 of them: left to the second pass).
-// MODE 1, for what the first pass left: the points of the window of half-width W are gathered once into LDS (more than
-//         WIDE_CAP of them: none are, and everything comes from the binned list) and give the first winner of a step.
-//         A winner whose circle stays within what the window guarantees is final; otherwise every point is a candidate:
-//         for 128 rows of cells at a time, every lane works out which columns of ITS two rows can hold a better
-//         candidate (inside the winner's circle, on the searched side of the line p a) and reads those rows' bounds,
-//         and the NW wavefronts share out the candidates of all rows in chunks of 64; their winners meet in LDS.
+// MODE 1, for what the first pass left: the points of the window of half-width W (of W / 2 or W / 4 when those are too many)
+//         are gathered once through LDS into WIDE_CAP / 64 registers per lane.  A winner whose circle stays within what
+//         the window guarantees is final; otherwise the points of the binned list are candidates: for 128 rows of cells at
+//         a time, every lane works out which columns of ITS two rows can hold a better candidate (inside the winner's
+//         circle, on the searched side of the line p a) and reads those rows' bounds, and the NW wavefronts share out the
+//         candidates of all rows in chunks of 64 (ranked in double when there is no winner yet: then in growing boxes of
+//         cells around p, so that the first winner comes from nearby); their winners meet in LDS.
 constexpr int WIDE_CAP = 384;
 
 #ifdef SVX_MESH_PROBE        // measurement aid: what the second pass spends on each point {slot, ring steps, searches of all points, 10 ns ticks, held candidates}

@@ -93,6 +93,23 @@ def test_high_gradient_points(ctx, rows, cols, threshold):
         assert np.array_equal(pts[off[f]:off[f + 1]], want)
 
 
+@pytest.mark.parametrize("n_frames", [1, 30, 31, 70])
+def test_high_gradient_points_frame_counts(ctx, n_frames):
+    """The per-frame offsets reach the host through mapped memory for up to 30 frames and by a copy beyond:
+    both against the oracle, twice in a row on one context (the second call with other counts)."""
+    rng = np.random.default_rng(n_frames)
+    for rows, cols in ((24, 40), (17, 33)):
+        batch = rng.integers(0, 256, size=(n_frames, rows, cols), dtype=np.uint8)
+        batch[n_frames // 2] = 0                             # a frame without any point
+        pts, off = ctx.high_gradient_points(dev(batch), 128)
+        pts = pts.cpu().numpy()
+        assert off[0] == 0 and len(off) == n_frames + 1 and len(pts) == off[-1]
+        for f in range(n_frames):
+            want = O.high_gradient_points(batch[f], 128)
+            assert off[f + 1] - off[f] == len(want)
+            assert np.array_equal(pts[off[f]:off[f + 1]], want)
+
+
 def test_high_gradient_points_capacity(ctx):
     rng = np.random.default_rng(9)
     g = rng.integers(0, 256, size=(40, 50), dtype=np.uint8)
