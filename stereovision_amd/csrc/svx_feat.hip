@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int FT_W = 64, FT_H = 16, FT_HALO = 3, FT_PITCH = FT_W + 2 * FT_HALO + 2;     // 72-byte LDS rows
+constexpr int FT_W = 64, FT_H = 4, FT_HALO = 3, FT_PITCH = FT_W + 2 * FT_HALO + 2;     // 72-byte LDS rows
 
 // True when the 16-bit ring mask holds a run of at least 9 set bits (with wrap-around).
 __device__ __forceinline__ bool ring_arc9(unsigned m) {
@@ -34,66 +34,82 @@ __device__ __forceinline__ void ring_masks(const int (&c)[16], int hi, int lo, u
     }
 }
 
+// A block scores a tile of FT_W x FT_H pixels in two steps: every pixel takes the FAST-9 test at the minimum threshold, and the
+// few that pass it (a twentieth of a textured frame) queue up in LDS and are scored by as many lanes as there are of them:
+// the adaptive test and the bisection, ten times the work of the first test, run in full wavefronts instead of in every
+// wavefront that holds one candidate.
 __global__ __launch_bounds__(256) void exfast_score_kernel(const uint8_t *__restrict__ img_all, int rows, int cols, int min_threshold,
                                                            float adaptivity, int round_sat, uint16_t *__restrict__ score_all) {
     __shared__ uint8_t tile[(FT_H + 2 * FT_HALO) * FT_PITCH];
+    __shared__ uint16_t queue[FT_W * FT_H];
+    __shared__ int queued;
     const long n = (long)rows * cols;
     const uint8_t *img = img_all + (long)blockIdx.z * n;
     uint16_t *score_map = score_all + (long)blockIdx.z * n;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    if (threadIdx.x == 0) queued = 0;
     for (int i = threadIdx.x; i < (FT_H + 2 * FT_HALO) * (FT_W + 2 * FT_HALO); i += 256) {
         const int ty = i / (FT_W + 2 * FT_HALO), tx = i - ty * (FT_W + 2 * FT_HALO);
         const int gy = y0 + ty - FT_HALO, gx = x0 + tx - FT_HALO;
         tile[ty * FT_PITCH + tx] = (gy >= 0 && gy < rows && gx >= 0 && gx < cols) ? img[(long)gy * cols + gx] : (uint8_t)0;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63;
-    const int x = x0 + lx;
     // ring offsets in the order of extendedfast.cpp:73-90
     constexpr int DX[16] = {-1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2};
     constexpr int DY[16] = {-3, -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2};
-#pragma unroll 1
-    for (int ly = threadIdx.x >> 6; ly < FT_H; ly += 4) {
-        const int y = y0 + ly;
+    // stage 1: FAST-9 at the minimum threshold on unsigned values (extendedfast.cpp:102); everything else scores 0
+    for (int p = threadIdx.x; p < FT_W * FT_H; p += 256) {
+        const int lx = p & (FT_W - 1), ly = p / FT_W, x = x0 + lx, y = y0 + ly;
         if (x >= cols || y >= rows) continue;
-        uint16_t result = 0;
+        bool candidate = false;
         if (x >= 3 && x < cols - 3 && y >= 3 && y < rows - 3) {
             const uint8_t *c = &tile[(ly + FT_HALO) * FT_PITCH + lx + FT_HALO];
             int ring[16];
-            int sum = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { ring[i] = c[DY[i] * FT_PITCH + DX[i]]; sum += ring[i]; }
+            for (int i = 0; i < 16; ++i) ring[i] = c[DY[i] * FT_PITCH + DX[i]];
             const int v = c[0];
-            // stage 1: FAST-9 at the minimum threshold on unsigned values (extendedfast.cpp:102)
             unsigned br, dk;
             ring_masks(ring, v + min_threshold, v - min_threshold, br, dk);
-            if (ring_arc9(br) || ring_arc9(dk)) {
-                // stage 2: adaptive threshold from the ring's mean absolute deviation (extendedfast.cpp:156-165)
-                const int avg = sum / 16;
-                int sad = 0;
+            candidate = ring_arc9(br) || ring_arc9(dk);
+        }
+        if (candidate) queue[atomicAdd(&queued, 1)] = (uint16_t)p;
+        else score_map[(long)y * cols + x] = 0;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < queued; q += 256) {
+        const int p = queue[q], lx = p & (FT_W - 1), ly = p / FT_W, x = x0 + lx, y = y0 + ly;
+        const uint8_t *c = &tile[(ly + FT_HALO) * FT_PITCH + lx + FT_HALO];
+        int ring[16];
+        int sum = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sad += abs(ring[i] - avg);
-                const float tf = (float)sad * adaptivity / 16.f;
-                const int thr_u = round_sat ? (sat_s8((int)rintf(tf)) & 0xff) : ((int)tf & 0xff);
-                const int thr_s = as_s8(thr_u);
-                const int mean5 = (v + c[-FT_PITCH] + c[FT_PITCH] + c[-1] + c[1]) / 5;      // extendedfast.h:18
-                const int cen_s = mean5 - 128;
+        for (int i = 0; i < 16; ++i) { ring[i] = c[DY[i] * FT_PITCH + DX[i]]; sum += ring[i]; }
+        const int v = c[0];
+        uint16_t result = 0;
+        // stage 2: adaptive threshold from the ring's mean absolute deviation (extendedfast.cpp:156-165)
+        const int avg = sum / 16;
+        int sad = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) ring[i] -= 128;                                 // signed domain
-                ring_masks(ring, sat_s8(cen_s + thr_s), sat_s8(cen_s - thr_s), br, dk);      // extendedfast.cpp:177-195
-                if (ring_arc9(br) || ring_arc9(dk)) {
-                    // score: largest threshold that still gives a corner, by bisection (extendedfast.cpp:197-231)
-                    int bmin = thr_u, bmax = 255, b = (bmax + bmin + 1) >> 1;
-                    for (;;) {
-                        ring_masks(ring, min(mean5 + b, 255) - 128, max(mean5 - b, 0) - 128, br, dk);
-                        if (ring_arc9(br) || ring_arc9(dk)) bmin = b;
-                        else bmax = b;
-                        if (bmin == bmax || bmin == bmax - 1) break;
-                        b = (bmax + bmin + 1) >> 1;
-                    }
-                    result = (uint16_t)(((bmin - thr_u) & 0xff) + 1);
-                }
+        for (int i = 0; i < 16; ++i) sad += abs(ring[i] - avg);
+        const float tf = (float)sad * adaptivity / 16.f;
+        const int thr_u = round_sat ? (sat_s8((int)rintf(tf)) & 0xff) : ((int)tf & 0xff);
+        const int thr_s = as_s8(thr_u);
+        const int mean5 = (v + c[-FT_PITCH] + c[FT_PITCH] + c[-1] + c[1]) / 5;      // extendedfast.h:18
+        const int cen_s = mean5 - 128;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ring[i] -= 128;                                 // signed domain
+        unsigned br, dk;
+        ring_masks(ring, sat_s8(cen_s + thr_s), sat_s8(cen_s - thr_s), br, dk);      // extendedfast.cpp:177-195
+        if (ring_arc9(br) || ring_arc9(dk)) {
+            // score: largest threshold that still gives a corner, by bisection (extendedfast.cpp:197-231)
+            int bmin = thr_u, bmax = 255, b = (bmax + bmin + 1) >> 1;
+            for (;;) {
+                ring_masks(ring, min(mean5 + b, 255) - 128, max(mean5 - b, 0) - 128, br, dk);
+                if (ring_arc9(br) || ring_arc9(dk)) bmin = b;
+                else bmax = b;
+                if (bmin == bmax || bmin == bmax - 1) break;
+                b = (bmax + bmin + 1) >> 1;
             }
+            result = (uint16_t)(((bmin - thr_u) & 0xff) + 1);
         }
         score_map[(long)y * cols + x] = result;
     }

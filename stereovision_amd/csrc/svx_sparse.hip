@@ -26,6 +26,46 @@ __device__ __forceinline__ int window_cost(const uint32_t *__restrict__ ref, con
     return cost;
 }
 
+// The matcher's form of the same cost: the reference window's 30 words are read once per left feature (they are the same in
+// every lane) and kept in registers, and a window that lies wholly inside the frame's flat index range, which is every
+// window but those of the last rows, is read without the guard, six consecutive words a row.
+struct Window6 { uint32_t w[30]; };
+__device__ __forceinline__ bool window6_inside(long n, int cols, int x, int y) {
+    return (long)(y - 2) * cols + (x - 2) >= 0 && (long)(y + 2) * cols + (x + 3) < n;
+}
+__device__ __forceinline__ Window6 window6_load(const uint32_t *__restrict__ img, long n, int cols, int x, int y) {
+    Window6 r;
+    if (window6_inside(n, cols, x, y)) {
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) r.w[6 * dy + k] = img[(long)(y + dy - 2) * cols + (x - 2) + k];
+    } else {
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) r.w[6 * dy + k] = ld_guard_u32(img, n, (long)(y + dy - 2) * cols + (x - 2) + k);
+    }
+    return r;
+}
+__device__ __forceinline__ int window6_cost(const Window6 &ref, const uint32_t *__restrict__ cmp, long n, int cols, int px, int py) {
+    int cost = 0;
+    if (window6_inside(n, cols, px, py)) {
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+            const uint32_t *row = cmp + (long)(py + dy - 2) * cols + (px - 2);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cost += popc32(ref.w[6 * dy + k] ^ row[k]);
+        }
+    } else {
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cost += popc32(ref.w[6 * dy + k] ^ ld_guard_u32(cmp, n, (long)(py + dy - 2) * cols + (px - 2) + k));
+    }
+    return cost;
+}
+
 // ---------------------------------------------------------------- a4 -----
 __global__ __launch_bounds__(256) void window_cost_kernel(const uint32_t *__restrict__ ref, const uint32_t *__restrict__ cmp, int rows, int cols,
                                                           const int32_t *__restrict__ ref_xy, const int32_t *__restrict__ cmp_xy, int n_pairs,
@@ -80,13 +120,14 @@ __global__ __launch_bounds__(256) void sparse_calc_costs_kernel(const uint32_t *
         return;
     }
     const long n = (long)rows * cols;
+    const Window6 ref = window6_load(cl, n, cols, __builtin_amdgcn_readfirstlane(f.xi), __builtin_amdgcn_readfirstlane(f.yi));
     unsigned long long best = ~0ull;   // (cost << 32) | r ; strict '<' in ascending r == minimum of this key
     for (int r = f.r_start + lane; r < f.r_end; r += 64) {
         const SparseRight g = R[r];
         const bool ok = g.x <= f.x && g.x >= f.x - (float)max_disparity && fabsf(f.y - g.y) <= y_tol &&
                         g.x >= 2.0f && g.x < (float)(cols - 2);
         if (ok) {
-            const int c = (int)(short)window_cost<6>(cl, cr, n, cols, f.xi, f.yi, g.xi, g.yi);
+            const int c = (int)(short)window6_cost(ref, cr, n, cols, g.xi, g.yi);
             const unsigned long long key = ((unsigned long long)(unsigned)(c + 32768) << 32) | (unsigned)r;
             best = key < best ? key : best;
         }
@@ -123,9 +164,10 @@ __global__ __launch_bounds__(256) void sparse_consistency_kernel(const uint32_t 
     const int y = f.yi;
     if (y < 2 || y >= rows - 2) return;
     const float limit = __fdiv_rn((float)(short)m_cost[l], uniqueness);
+    const Window6 ref = window6_load(cr, n, cols, __builtin_amdgcn_readfirstlane(g.xi), __builtin_amdgcn_readfirstlane(g.yi));
     bool reject = false;
     for (int x = start_x + lane * lr_step; x < end_x; x += 64 * lr_step) {
-        const int c = (int)(short)window_cost<6>(cr, cl, n, cols, g.xi, g.yi, x, y);
+        const int c = (int)(short)window6_cost(ref, cl, n, cols, x, y);
         if ((float)c < limit && abs(x - f.xi) > lr_step) reject = true;
     }
     if (__any(reject) && lane == 0) m_first[l] = -1;
@@ -137,8 +179,9 @@ __global__ __launch_bounds__(256) void sparse_consistency_kernel(const uint32_t 
 // >= j for j up to the last row below rows - 1 that holds a feature, and n_right beyond it.  The state rule (top rows
 // skipped, everything from the first feature in the bottom rows on invalidated) depends on the order only through the
 // row, because the list is sorted.
+// row_first (may be null): row_first[j * row_pitch] = index of the first right feature in row j or below, from the bucket index.
 __global__ void sparse_prepare_kernel(const int32_t *__restrict__ kl, int nl, const int32_t *__restrict__ kr, int nr, int rows, float y_tol,
-                                      SparseLeft *__restrict__ L, SparseRight *__restrict__ R) {
+                                      const int *__restrict__ row_first, int row_pitch, SparseLeft *__restrict__ L, SparseRight *__restrict__ R) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nr) {
         SparseRight g;
@@ -147,6 +190,7 @@ __global__ void sparse_prepare_kernel(const int32_t *__restrict__ kl, int nl, co
     }
     if (i >= nl) return;
     auto first_row_at_least = [&](int j) {            // lower bound over the right rows
+        if (row_first) return row_first[j * row_pitch];
         int lo = 0, hi = nr;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -203,6 +247,7 @@ __global__ __launch_bounds__(256) void sparse_calc_costs_indexed_kernel(const ui
         return;
     }
     const long n = (long)rows * cols;
+    const Window6 ref = window6_load(cl, n, cols, __builtin_amdgcn_readfirstlane(f.xi), __builtin_amdgcn_readfirstlane(f.yi));
     const int x_lo = max(f.xi - max_disparity, 2), x_hi = min(f.xi, cols - 3);
     unsigned long long best = ~0ull;
     if (x_lo <= x_hi) {
@@ -214,7 +259,7 @@ __global__ __launch_bounds__(256) void sparse_calc_costs_indexed_kernel(const ui
                 const bool ok = g.x <= f.x && g.x >= f.x - (float)max_disparity && fabsf(f.y - g.y) <= y_tol &&
                                 g.x >= 2.0f && g.x < (float)(cols - 2);
                 if (ok) {
-                    const int c = (int)(short)window_cost<6>(cl, cr, n, cols, f.xi, f.yi, g.xi, g.yi);
+                    const int c = (int)(short)window6_cost(ref, cr, n, cols, g.xi, g.yi);
                     const unsigned long long key = ((unsigned long long)(unsigned)(c + 32768) << 32) | (unsigned)r;
                     best = key < best ? key : best;
                 }
@@ -250,17 +295,20 @@ int svx_sparse_match_lists(svx_ctx *ctx, const uint32_t *census_left, const uint
     SparseLeft *dl = (SparseLeft *)ws;
     SparseRight *dr = (SparseRight *)((char *)ws + ro_off);
     int *bucket_first = (int *)((char *)ws + bf_off);
-    sparse_prepare_kernel<<<svx_cdiv(std::max(n_left, n_right), 256), 256, 0, ctx->stream>>>(left_xy, n_left, right_xy, n_right, rows, y_tolerance, dl, dr);
-    SVX_LAUNCH_CHECK(ctx, "sparse_prepare_kernel");
-    const unsigned grid = svx_cdiv(n_left, 4);
+    const unsigned grid = svx_cdiv(n_left, 4), prep_grid = svx_cdiv(std::max(n_left, n_right), 256);
     // (a tolerance of four rows or more, or a disparity range wider than the frame, keeps the kernel that walks whole rows)
     if (y_tolerance >= 0.0f && y_tolerance < (float)(SP_MAX_TOL_ROWS + 1) && max_disparity >= 0 && max_disparity < cols) {
         sparse_bucket_index_kernel<<<svx_cdiv((long)rows * (nb + 1), 256), 256, 0, ctx->stream>>>(right_xy, n_right, rows, nb, bucket_first);
         SVX_LAUNCH_CHECK(ctx, "sparse_bucket_index_kernel");
+        // (the index's first column is the row-offset table the records are built from)
+        sparse_prepare_kernel<<<prep_grid, 256, 0, ctx->stream>>>(left_xy, n_left, right_xy, n_right, rows, y_tolerance, bucket_first, nb + 1, dl, dr);
+        SVX_LAUNCH_CHECK(ctx, "sparse_prepare_kernel");
         sparse_calc_costs_indexed_kernel<<<grid, 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, dl, n_left, dr, bucket_first, nb,
                                                                        (int)y_tolerance, max_disparity, y_tolerance, first_dev, cost_dev);
         SVX_LAUNCH_CHECK(ctx, "sparse_calc_costs_indexed_kernel");
     } else {
+        sparse_prepare_kernel<<<prep_grid, 256, 0, ctx->stream>>>(left_xy, n_left, right_xy, n_right, rows, y_tolerance, nullptr, 0, dl, dr);
+        SVX_LAUNCH_CHECK(ctx, "sparse_prepare_kernel");
         sparse_calc_costs_kernel<<<grid, 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, dl, n_left, dr, max_disparity, y_tolerance, first_dev, cost_dev);
         SVX_LAUNCH_CHECK(ctx, "sparse_calc_costs_kernel");
     }
