@@ -17,8 +17,8 @@ MODEL = {
     "plane_fit_kernel": (n_tri, 24 + 12 + 12, "triangle: six corner coordinates 24 B, three disparities 12 B, plane 12 B"),
     "raster_owner_kernel": (px, 4, "pixel: one 4-byte owner (atomic minimum of the triangle index), plus 24 B per triangle"),
     "raster_eval_kernel": (px, 4 + 4, "pixel: owner 4 B read, prior 4 B written (plane 12 B per triangle through the cache)"),
-    "sparse_calc_costs": (n_left, 40 * 2 * 30 * 4, "left feature: about 40 candidate windows of 30 census words on either side (cache traffic: the words of neighbouring windows overlap)"),
-    "sparse_consistency_kernel": (n_sup, 70 * 2 * 30 * 4, "matched feature: 70 windows of 30 census words on either side (cache traffic)"),
+    "sparse_calc_costs": (n_left, (40 + 1) * 30 * 4, "left feature: its window of 30 census words once, about 40 candidate windows of 30 words (cache traffic: the words of neighbouring windows overlap)"),
+    "sparse_consistency_kernel": (n_sup, (70 + 1) * 30 * 4, "matched feature: its right window once, 70 left windows of 30 census words (cache traffic)"),
     "support_resampling_kernel": ((ROWS // 64 + 1) * (COLS // 64 + 1), 70 * 2 * 121 * 4, "grid cell with an invalid match: 70 disparities x 11 x 11 census words on either side (cache traffic)"),
     "census5x5_tile_kernel": (px, 1 + 4, "pixel: 1 B in, 4 B out"),
     "exfast_score_kernel": (px, 1 + 2, "pixel: 1 B in, 2-byte score out"),
