@@ -35,6 +35,60 @@ __device__ __forceinline__ int epipolar_search(const uint32_t *__restrict__ cl, 
     return best == ~0ull ? 0 : (int)(unsigned)(best & 0xffffffffu);
 }
 
+// The same search with the window's loops unrolled (A = 2 HALF + 1 known at compile time): the 2 A words of a window row are
+// independent reads in flight together, where the general form waits for every pair of words in turn (121 round trips a
+// disparity at A = 11), and the left words come from addresses that are the same in every lane.  INSIDE: the point's window
+// lies inside the frame at every disparity (all points but those next to the frame's borders): no guard, no clipping.
+// Otherwise the clipping rules of the general form as predicates: rows outside the frame are skipped, a right column at or
+// beyond cols ends its row, every read is a flat index with zeros outside the frame.  x, y: the same in every lane.
+template <int HALF, bool INSIDE>
+__device__ __forceinline__ int epipolar_search_unrolled(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                                        int margin, int x, int y, int max_disp, int lane) {
+    const long n = (long)rows * cols;
+    unsigned long long best = ~0ull;
+    for (int d0 = 0; d0 < max_disp && x - d0 >= HALF + margin; d0 += 64) {
+        const int d = d0 + lane, i = x - d;
+        const bool live = d < max_disp && i >= HALF + margin;
+        const int ic = live ? i : x - d0;                 // (a lane without a disparity reads the window of the round's first one)
+        unsigned cost = 0;
+#pragma unroll
+        for (int m = -HALF; m <= HALF; ++m) {
+            const long ro = (long)(y + m) * cols;
+            if (INSIDE) {
+                const uint32_t *lrow = cl + ro + (x - HALF), *rrow = cr + ro + (ic - HALF);
+#pragma unroll
+                for (int k = 0; k <= 2 * HALF; ++k) cost += popc32(lrow[k] ^ rrow[k]);
+            } else if (y + m >= 0 && y + m < rows) {
+#pragma unroll
+                for (int k = -HALF; k <= HALF; ++k) {
+                    const unsigned c = popc32(ld_guard_u32(cl, n, ro + x + k) ^ ld_guard_u32(cr, n, ro + ic + k));
+                    cost += ic + k < cols ? c : 0u;
+                }
+            }
+        }
+        const unsigned long long key = live ? ((unsigned long long)cost << 32) | (unsigned)d : ~0ull;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = __shfl_xor(best, s, 64);
+        best = o < best ? o : best;
+    }
+    return best == ~0ull ? 0 : (int)(unsigned)(best & 0xffffffffu);
+}
+
+// Picks the form: x, y are made wavefront-uniform (one point per wavefront).
+__device__ __forceinline__ int epipolar_search_point(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
+                                                     int half, int margin, int x, int y, int max_disp, int lane) {
+    x = __builtin_amdgcn_readfirstlane(x);
+    y = __builtin_amdgcn_readfirstlane(y);
+    if (half == 5 && margin >= 0) {
+        if (y - 5 >= 0 && y + 5 < rows && x + 5 < cols && x >= 5) return epipolar_search_unrolled<5, true>(cl, cr, rows, cols, margin, x, y, max_disp, lane);
+        return epipolar_search_unrolled<5, false>(cl, cr, rows, cols, margin, x, y, max_disp, lane);
+    }
+    return epipolar_search(cl, cr, rows, cols, half, margin, x, y, max_disp, lane);
+}
+
 __device__ __forceinline__ int single_pixel_cost(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
                                                  int x, int y, int d) {
     const long n = (long)rows * cols;
@@ -48,7 +102,7 @@ __global__ __launch_bounds__(256) void epipolar_match_kernel(const uint32_t *__r
     const int lane = threadIdx.x & 63;
     if (p >= n_pts) return;
     const int x = pts_xy[2 * p], y = pts_xy[2 * p + 1];
-    const int d = epipolar_search(cl, cr, rows, cols, half, margin, x, y, max_disp, lane);
+    const int d = epipolar_search_point(cl, cr, rows, cols, half, margin, x, y, max_disp, lane);
     if (lane == 0) {
         out_disp[p] = (float)d;
         out_cost[p] = (int8_t)single_pixel_cost(cl, cr, rows, cols, x, y, d);
@@ -71,7 +125,7 @@ __global__ __launch_bounds__(256) void support_resampling_kernel(const uint32_t 
     bool inv_ok = false;
     int ix = inv_x[c], iy = inv_y[c], d = 0;
     if ((int)inv_c[c] > t_high) {          // wavefront-uniform
-        d = epipolar_search(cl, cr, rows, cols, half, margin, ix, iy, max_disp, lane);
+        d = epipolar_search_point(cl, cr, rows, cols, half, margin, ix, iy, max_disp, lane);
         inv_ok = (int)(int8_t)single_pixel_cost(cl, cr, rows, cols, ix, iy, d) < t_low;
     }
     if (lane == 0) {
