@@ -18,3 +18,10 @@ for mx in (1, 0):
     print("right view alone, 64 frames 1232x368 / 128, two-word descriptors, matrix cores %s: %.3f ms" % ("on" if mx else "off", (time.perf_counter() - t0) * 100))
     if mx: keep = out.clone()
 print("equal:", bool(torch.equal(keep, out)))
+ctx.set_option(S.OPT_MATRIX_CORES, -1)
+for name, call in (("left view alone", lambda: ctx.dense_wta(cl, cr, D, words=2, view=S.VIEW_LEFT)), ("both views", lambda: ctx.dense_wta_both(cl, cr, D, words=2))):
+    call()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): call()
+    torch.cuda.synchronize()
+    print("%s, matrix cores on: %.3f ms" % (name, (time.perf_counter() - t0) * 100))
