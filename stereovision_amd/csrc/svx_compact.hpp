@@ -9,6 +9,20 @@
 
 namespace {          // one private copy per translation unit that includes this header
 
+// Running total of x over the wavefront's lanes, this lane included: inside the rows of 16 lanes by DPP shifts, then the last
+// lane of a row (of the first two rows) is added to the rows behind it.
+__device__ __forceinline__ unsigned svx_wave_scan_u32(unsigned x) {
+    const int v = (int)x;
+    int t = v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);                    // row_shr:1
+    t += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);                            // row_shr:2
+    t += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true);                            // row_shr:3
+    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xe, false);                           // row_shr:4, lanes 4..15 of a row
+    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xc, false);                           // row_shr:8, lanes 8..15
+    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, false);                           // row_bcast:15, rows 1 and 3
+    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, false);                           // row_bcast:31, rows 2 and 3
+    return (unsigned)t;
+}
+
 template <class Pred>
 __global__ __launch_bounds__(256) void compact_count_kernel(Pred pred, int rows, int cols, unsigned *__restrict__ line_count) {
     __shared__ unsigned wave_sum[4];
@@ -33,11 +47,7 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(unsigned *__restrict
     for (int base = 0; base < n_lines; base += 1024) {
         const int i = base + threadIdx.x;
         const unsigned v = i < n_lines ? line_count[i] : 0u;
-        unsigned s = v;                                   // inclusive scan inside the wavefront
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned t = __shfl_up(s, o, 64);
-            if (lane >= o) s += t;
-        }
+        const unsigned s = svx_wave_scan_u32(v);          // inclusive scan inside the wavefront
         if (lane == 63) wave_tot[wave] = s;
         __syncthreads();
         unsigned before = carry;
@@ -60,44 +70,54 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(unsigned *__restrict
     }
 }
 
-// Exclusive scan of src[0..n) into v[0..n) by one workgroup (src == v: in place), four consecutive values per thread and round
-// (one 16-byte load a lane); v[n] receives the total, and so does the host (mail->v[0]) when `mail` is given.  v and src must be
-// 16-byte aligned.
+// Exclusive scan of src[0..n) into v[0..n) by one workgroup (src == v: in place), sixteen consecutive values per thread and
+// round (four 16-byte loads a lane, all in flight); v[n] receives the total, and so does the host (mail->v[0]) when `mail` is
+// given.  v and src must be 16-byte aligned.
 __global__ __launch_bounds__(1024) void scan4_kernel(unsigned *v, int n, const unsigned *src, svx_mail *mail, unsigned seq) {
     __shared__ unsigned wave_tot[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned carry = 0;
     int buf = 0;
-    for (int base = 0; base < n; base += 4096, buf ^= 1) {
-        const int i0 = base + 4 * (int)threadIdx.x;
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (i0 + 3 < n) x = *(const uint4 *)(src + i0);
-        else {
-            if (i0 < n) x.x = src[i0];
-            if (i0 + 1 < n) x.y = src[i0 + 1];
-            if (i0 + 2 < n) x.z = src[i0 + 2];
+    for (int base = 0; base < n; base += 16384, buf ^= 1) {
+        const int i0 = base + 16 * (int)threadIdx.x;
+        unsigned x[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 4 * q;
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (i + 3 < n) t = *(const uint4 *)(src + i);
+            else {
+                if (i < n) t.x = src[i];
+                if (i + 1 < n) t.y = src[i + 1];
+                if (i + 2 < n) t.z = src[i + 2];
+            }
+            x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
         }
-        const unsigned sum = x.x + x.y + x.z + x.w;
-        unsigned incl = sum;                              // inclusive scan of the threads' sums inside the wavefront
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
+        unsigned sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += x[q];
+        const unsigned incl = svx_wave_scan_u32(sum);     // inclusive scan of the threads' sums inside the wavefront
         if (lane == 63) wave_tot[buf][wave] = incl;
         __syncthreads();                                  // (the buffers alternate, so one meeting a round is enough)
         unsigned before = carry, all = 0;
+#pragma unroll
         for (int w = 0; w < 16; ++w) {
             const unsigned t = wave_tot[buf][w];
             before += w < wave ? t : 0u;
             all += t;
         }
-        const unsigned e0 = before + incl - sum;
-        const uint4 out = make_uint4(e0, e0 + x.x, e0 + x.x + x.y, e0 + x.x + x.y + x.z);
-        if (i0 + 3 < n) *(uint4 *)(v + i0) = out;
-        else {
-            if (i0 < n) v[i0] = out.x;
-            if (i0 + 1 < n) v[i0 + 1] = out.y;
-            if (i0 + 2 < n) v[i0 + 2] = out.z;
+        unsigned e = before + incl - sum;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 4 * q;
+            const uint4 out = make_uint4(e, e + x[4 * q], e + x[4 * q] + x[4 * q + 1], e + x[4 * q] + x[4 * q + 1] + x[4 * q + 2]);
+            e = out.w + x[4 * q + 3];
+            if (i + 3 < n) *(uint4 *)(v + i) = out;
+            else {
+                if (i < n) v[i] = out.x;
+                if (i + 1 < n) v[i + 1] = out.y;
+                if (i + 2 < n) v[i + 2] = out.z;
+            }
         }
         carry += all;
     }

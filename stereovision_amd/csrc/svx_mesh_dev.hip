@@ -79,19 +79,6 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
     const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)x, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
     return min(min(r0, r1), min(r2, r3));
 }
-// Running total of x over the wavefront's lanes, this lane included: inside the rows of 16 lanes by DPP shifts, then the
-// last lane of a row (of the first two rows) is added to the rows behind it.
-__device__ __forceinline__ unsigned wave_scan_u32(unsigned x) {
-    const int v = (int)x;
-    int t = v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);                    // row_shr:1
-    t += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);                            // row_shr:2
-    t += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true);                            // row_shr:3
-    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xe, false);                           // row_shr:4, lanes 4..15 of a row
-    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xc, false);                           // row_shr:8, lanes 8..15
-    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, false);                           // row_bcast:15, rows 1 and 3
-    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, false);                           // row_bcast:31, rows 2 and 3
-    return (unsigned)t;
-}
 // float -> unsigned with the same order
 __device__ __forceinline__ unsigned ordered_bits(float f) {
     const unsigned u = __float_as_uint(f);
@@ -234,7 +221,7 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                 const int xa = max(cx - We, 0), xb = min(cx + We + 1, gw), ya = max(cy - We, 0), yb = min(cy + We + 1, gh);
                 w_s = 0; w_cnt = 0;
                 if (ya + lane < yb) { w_s = (int)cell_start[(ya + lane) * gw + xa]; w_cnt = (int)cell_start[(ya + lane) * gw + xb] - w_s; }
-                w_incl = (int)wave_scan_u32((unsigned)w_cnt);  // running total over the rows
+                w_incl = (int)svx_wave_scan_u32((unsigned)w_cnt);  // running total over the rows
                 n_wide = __builtin_amdgcn_readlane(w_incl, 63);
                 if (n_wide <= WIDE_CAP && yb - ya <= 64) break;
                 if (attempt == 2) { n_wide = -1; break; }     // still too many: nothing held on chip, nothing guaranteed
@@ -332,7 +319,7 @@ __global__ __launch_bounds__(64 * NW) void ring_wave_kernel(const int2 *__restri
                         }
                     }
                 }
-                const int incl0 = (int)wave_scan_u32((unsigned)cnt[0]), incl1 = (int)wave_scan_u32((unsigned)cnt[1]);
+                const int incl0 = (int)svx_wave_scan_u32((unsigned)cnt[0]), incl1 = (int)svx_wave_scan_u32((unsigned)cnt[1]);
                 const int total0 = __builtin_amdgcn_readlane(incl0, 63), total = total0 + __builtin_amdgcn_readlane(incl1, 63);
                 const int at0 = incl0 - cnt[0], at1 = total0 + incl1 - cnt[1];          // where each row starts among the round's candidates
                 for (int base = 64 * wave; base < total; base += 256 * NW) {          // four loads in flight
