@@ -635,9 +635,11 @@ class Context:
         return xyz[:n], (pix[:n] if pix is not None else None), off
 
     # ---- the full pipeline ----
-    def high_perf_stereo(self, left, right, params, disparity_map):
+    def high_perf_stereo(self, left, right, params, disparity_map, capacity=None):
         """highPerfStereo() on one rectified pair: disparity_map ([rows, cols] float32, in/out) is updated in place;
-        returns the computed points [n, 2] int32 (host): the high-gradient points, then the mesh vertices."""
+        returns the computed points [n, 2] int32 (host): the high-gradient points, then the mesh vertices.  capacity: room
+        for points in the host buffer handed to the library (default: enough for all); with less, the first `capacity`
+        points come back and `self.last_point_count` holds how many there were."""
         t = self._torch
         _check_dev(left, t.uint8, "left"); _check_dev(right, t.uint8, "right"); _check_dev(disparity_map, t.float32, "disparity_map")
         if left.dim() != 2:
@@ -647,11 +649,12 @@ class Context:
         if left.shape != disparity_map.shape:
             raise SvxError(-2, "disparity map do not have the same dimensions as the input images!")
         rows, cols = left.shape
-        cap = 2 * rows * cols
-        pts = np.zeros((cap, 2), np.int32)
+        cap = 2 * rows * cols if capacity is None else int(capacity)
+        pts = np.zeros((max(cap, 1), 2), np.int32)
         n = _i(0)
         self._call("svx_high_perf_stereo", _dptr(left), _dptr(right), rows, cols, C.byref(params), _dptr(disparity_map),
                    pts.ctypes.data_as(_vp), cap, C.byref(n))
+        self.last_point_count = n.value
         return pts[:min(n.value, cap)].copy()
 
     def high_perf_stereo_batch(self, left, right, params, disparity_maps, n_threads=4):

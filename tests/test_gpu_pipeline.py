@@ -107,6 +107,28 @@ def test_pipeline_with_the_mesh_on_the_host(ctx, rows, cols, seed, over):
     assert np.array_equal(dev_pts, host_pts) and np.array_equal(dev_map, host_map)
 
 
+def test_pipeline_point_buffer_smaller_than_the_points(ctx):
+    """The caller's point buffer may hold fewer points than the frame computes: the first `capacity` of them come back (the
+    high-gradient points, then the mesh vertices), the count is the whole number, the map does not depend on the buffer."""
+    import stereovision_amd as S
+    from stereovision_amd import synth
+    p = S.StereoParameters.reference_defaults(maxDisp=32, nIters=2, gradThreshold=30)
+    left, right, _ = synth.stereo_pair(120, 250, 32, 31)
+    full_map = dev(np.zeros(left.shape, np.float32))
+    full = ctx.high_perf_stereo(dev(left), dev(right), p, full_map)
+    total = ctx.last_point_count
+    assert total == len(full) > 200
+    key = full[:, 1].astype(np.int64) * 4096 + full[:, 0]
+    n_hg = int(np.flatnonzero(key[1:] < key[:-1])[0]) + 1          # the mesh vertices start where the raster order breaks
+    for cap in (0, 1, 10, n_hg - 5, n_hg, n_hg + 7, total - 1, total, total + 100):
+        m = dev(np.zeros(left.shape, np.float32))
+        got = ctx.high_perf_stereo(dev(left), dev(right), p, m, capacity=cap)
+        assert ctx.last_point_count == total
+        assert len(got) == min(cap, total)
+        assert np.array_equal(got, full[:min(cap, total)]), cap
+        assert torch.equal(m, full_map)
+
+
 def test_pipeline_recovers_the_scene(ctx):
     """On a pair generated from a known piecewise-planar field, most accepted high-gradient pixels carry that field."""
     import stereovision_amd as S
