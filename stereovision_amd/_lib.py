@@ -635,6 +635,13 @@ class Context:
         return xyz[:n], (pix[:n] if pix is not None else None), off
 
     # ---- the full pipeline ----
+    def _host_points(self, n):
+        """Host buffer for n computed points, kept between calls (fresh pages cost a fault each when the library fills them)."""
+        buf = getattr(self, "_points_buf", None)
+        if buf is None or len(buf) < n:
+            buf = self._points_buf = np.empty((n, 2), np.int32)
+        return buf[:n]
+
     def high_perf_stereo(self, left, right, params, disparity_map, capacity=None):
         """highPerfStereo() on one rectified pair: disparity_map ([rows, cols] float32, in/out) is updated in place;
         returns the computed points [n, 2] int32 (host): the high-gradient points, then the mesh vertices.  capacity: room
@@ -650,27 +657,27 @@ class Context:
             raise SvxError(-2, "disparity map do not have the same dimensions as the input images!")
         rows, cols = left.shape
         cap = 2 * rows * cols if capacity is None else int(capacity)
-        pts = np.zeros((max(cap, 1), 2), np.int32)
+        pts = self._host_points(max(cap, 1))
         n = _i(0)
         self._call("svx_high_perf_stereo", _dptr(left), _dptr(right), rows, cols, C.byref(params), _dptr(disparity_map),
                    pts.ctypes.data_as(_vp), cap, C.byref(n))
         self.last_point_count = n.value
         return pts[:min(n.value, cap)].copy()
 
-    def high_perf_stereo_batch(self, left, right, params, disparity_maps, n_threads=4):
+    def high_perf_stereo_batch(self, left, right, params, disparity_maps, n_threads=4, copy=True):
         """svx_high_perf_stereo_batch on [frames, rows, cols] batches: disparity_maps updated in place; returns one [n, 2]
-        int32 point array per frame."""
+        int32 point array per frame (copy=False: views into a buffer that the next call overwrites)."""
         t = self._torch
         _check_dev(left, t.uint8, "left"); _check_dev(right, t.uint8, "right"); _check_dev(disparity_maps, t.float32, "disparity_maps")
         if left.dim() != 3 or left.shape != right.shape or left.shape != disparity_maps.shape:
             raise SvxError(-2, "Input images do not have the same dimensions!")
         f, rows, cols = left.shape
         cap = 2 * rows * cols
-        pts = np.zeros((f, cap, 2), np.int32)
+        pts = self._host_points(f * cap).reshape(f, cap, 2)
         n = (_i * f)()
         self._call("svx_high_perf_stereo_batch", _dptr(left), _dptr(right), rows, cols, f, C.byref(params), _dptr(disparity_maps),
                    pts.ctypes.data_as(_vp), cap, n, int(n_threads))
-        return [pts[i, :min(n[i], cap)].copy() for i in range(f)]
+        return [pts[i, :min(n[i], cap)].copy() if copy else pts[i, :min(n[i], cap)] for i in range(f)]
 
     PIPELINE_STAGES = ("crop+equalise", "gradient+points", "alter+exFAST", "census", "sparse match", "support upload",
                        "mesh+prior", "cost+refine", "resampling", "finalise")
