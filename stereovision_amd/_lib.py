@@ -642,11 +642,12 @@ class Context:
             buf = self._points_buf = np.empty((n, 2), np.int32)
         return buf[:n]
 
-    def high_perf_stereo(self, left, right, params, disparity_map, capacity=None):
+    def high_perf_stereo(self, left, right, params, disparity_map, capacity=None, copy=True):
         """highPerfStereo() on one rectified pair: disparity_map ([rows, cols] float32, in/out) is updated in place;
         returns the computed points [n, 2] int32 (host): the high-gradient points, then the mesh vertices.  capacity: room
         for points in the host buffer handed to the library (default: enough for all); with less, the first `capacity`
-        points come back and `self.last_point_count` holds how many there were."""
+        points come back and `self.last_point_count` holds how many there were.  copy=False: a view into a buffer that the
+        next call overwrites."""
         t = self._torch
         _check_dev(left, t.uint8, "left"); _check_dev(right, t.uint8, "right"); _check_dev(disparity_map, t.float32, "disparity_map")
         if left.dim() != 2:
@@ -662,7 +663,7 @@ class Context:
         self._call("svx_high_perf_stereo", _dptr(left), _dptr(right), rows, cols, C.byref(params), _dptr(disparity_map),
                    pts.ctypes.data_as(_vp), cap, C.byref(n))
         self.last_point_count = n.value
-        return pts[:min(n.value, cap)].copy()
+        return pts[:min(n.value, cap)].copy() if copy else pts[:min(n.value, cap)]
 
     def high_perf_stereo_batch(self, left, right, params, disparity_maps, n_threads=4, copy=True):
         """svx_high_perf_stereo_batch on [frames, rows, cols] batches: disparity_maps updated in place; returns one [n, 2]

@@ -12,7 +12,7 @@ for it in (2, 1, 2, 3, 2):
     ts = []
     for _ in range(40):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        ctx.high_perf_stereo(l, r, p, out)
+        ctx.high_perf_stereo(l, r, p, out, copy=False)      # (the library's call alone: no copy of the points on the Python side)
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
     ts = np.array(ts)
     print("nIters", it, "ms per frame: min %.2f median %.2f mean %.2f max %.2f" % (ts.min(), np.median(ts), ts.mean(), ts.max()), "first five", np.round(ts[:5], 2))
