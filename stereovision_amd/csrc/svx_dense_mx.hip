@@ -23,7 +23,7 @@ typedef int mx_v8i __attribute__((ext_vector_type(8)));
 typedef float mx_v16f __attribute__((ext_vector_type(16)));
 
 #ifndef MX_X
-#define MX_X 0      // measurement aid: bit 0 drops the staging work, bit 1 the winner selection, bit 2 the meeting point (results are wrong then)
+#define MX_X 0      // measurement aid: bit 0 drops the staging work, bit 1 the winner selection, bit 2 the meeting point, bit 3 the leaving row's staging (results are wrong then)
 #endif
 #ifndef MX_PLANE_PAD
 #define MX_PLANE_PAD 0      // measurement aid: extra pixels between the two planes of a staged row
@@ -343,7 +343,7 @@ __device__ __forceinline__ void mx_row(mx_v16f (&acc)[T], const MxPtrs<WORDS> &p
         // this thread's share of the next staged rows
         mx_static_for(std::make_integer_sequence<int, 2 * G::ROUNDS>{}, [&](auto v_c) __attribute__((always_inline)) {
             constexpr int v = decltype(v_c)::value;
-            if constexpr (mx_unit_step<T, TG, WORDS, PER>(v) == s && !(MX_X & 1)) {
+            if constexpr (mx_unit_step<T, TG, WORDS, PER>(v) == s && !(MX_X & 1) && !((MX_X & 8) && v >= G::ROUNDS)) {
                 constexpr bool old = v >= G::ROUNDS;                  // entering row first, then the leaving row
                 constexpr int i = old ? v - G::ROUNDS : v;
                 constexpr int kind = i < G::FR ? 0 : i < G::FR + G::FL ? 1 : 2;     // right words, left words, left-over words
