@@ -100,6 +100,10 @@ int svx_mesh_device_triangles(svx_ctx *ctx, const int32_t *pts_xy, int n, int ro
 int svx_sparse_match_lists(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, const int32_t *left_xy,
                            int n_left, const int32_t *right_xy, int n_right, int max_disparity, float y_tolerance, float uniqueness,
                            int left_right_step, int *first_dev, int *cost_dev);      // svx_sparse.hip: device key-point lists in raster order
+int svx_cost_eval_refine(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, const int32_t *pts_xy, int n_pts,
+                         const float *disparities, int rows, int cols, int t_low, int t_high, unsigned occ_grid_size,
+                         float *final_disparities, int8_t *final_costs, int32_t *conf_x, int32_t *conf_y, float *conf_d, int8_t *conf_c,
+                         int32_t *inv_x, int32_t *inv_y, int8_t *inv_c);      // svx_prior.hip: svx_cost_eval + svx_refine without the cost map
 int svx_static_scratch_locate(svx_ctx *ctx);   // svx_dense.hip: finds this device's copy of the fixed scratch array
 
 // Matrix-core form of the dense search on two-word descriptors (svx_dense_mx.hip).

@@ -204,10 +204,9 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     // crop to multiples of 16, equalise, gradient, high-gradient point set (.cpp:245-280)
     SVX_TRY(svx_crop16(ctx, left, rows, cols, 1, L));
     SVX_TRY(svx_crop16(ctx, right, rows, cols, 1, Rr));
-    if (prm->applyHistEqualization) {
-        SVX_TRY(svx_equalize_hist(ctx, L, L, R, Cc, 1));
-        SVX_TRY(svx_equalize_hist(ctx, Rr, Rr, R, Cc, 1));
-    }
+    // the frame's size is a multiple of 256, so the pair's images lie one behind the other in the arena and one launch serves both
+    if (Rr != L + n || Ra != La + n || cR != cL + n) return svx_fail(ctx, SVX_ERR_HIP, "svx_high_perf_stereo: arena layout");
+    if (prm->applyHistEqualization) SVX_TRY(svx_equalize_hist(ctx, L, L, R, Cc, 2));
     clk.mark(0);
     SVX_TRY(svx_laplacian_abs(ctx, L, grad, R, Cc, 1, prm->kernelSize, (double)prm->scale, (double)prm->delta));
     int off[2] = {0, 0};
@@ -227,8 +226,7 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
 
     clk.mark(1);
     // altered copies for the detector only (.cpp:296-335)
-    SVX_HIP(ctx, hipMemcpyAsync(La, L, n, hipMemcpyDeviceToDevice, ctx->stream));
-    SVX_HIP(ctx, hipMemcpyAsync(Ra, Rr, n, hipMemcpyDeviceToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(La, L, 2 * n, hipMemcpyDeviceToDevice, ctx->stream));
     if (prm->invertRows || prm->traceLines) {
         SVX_TRY(svx_alter_rows(ctx, La, R, Cc, 1, prm->invertRows, prm->nbRows, prm->traceLines, prm->nbLines, prm->lineSize));
         SVX_TRY(svx_alter_rows(ctx, Ra, R, Cc, 1, prm->invertRows, prm->nbRows, prm->traceLines, prm->nbLines, prm->lineSize));
@@ -240,8 +238,7 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
     SVX_TRY(svx_exfast_detect(ctx, Ra, R, Cc, 1, prm->minThreshold, (float)prm->adaptivity, 0, kpr, respr, (int)n, offr));
     const int nl = offl[1], nr = offr[1];
     clk.mark(2);
-    SVX_TRY(svx_census5x5_u8(ctx, L, cL, R, Cc, 1, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST));
-    SVX_TRY(svx_census5x5_u8(ctx, Rr, cR, R, Cc, 1, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST));
+    SVX_TRY(svx_census5x5_u8(ctx, L, cL, R, Cc, 2, SVX_CENSUS_SSE24 | SVX_CENSUS_ZERO_REST));
 
     clk.mark(3);
     // sparse matching of the key points (.cpp:354-355, :390): the detector's lists stay on the device, where they are in
@@ -316,13 +313,14 @@ SVX_API int svx_high_perf_stereo(svx_ctx *ctx, const uint8_t *left, const uint8_
             }
         }
         clk.mark(6);
-        SVX_HIP(ctx, hipMemsetAsync(costs, t_high & 0xff, n, ctx->stream));                             // .cpp:573
-        if (const int band = svx_opt(ctx, SVX_OPT_PRIOR_BAND_RADIUS); band > 0)                         // build extension: search d0 - band .. d0 + band
+        if (const int band = svx_opt(ctx, SVX_OPT_PRIOR_BAND_RADIUS); band > 0) {                       // build extension: search d0 - band .. d0 + band
+            SVX_HIP(ctx, hipMemsetAsync(costs, t_high & 0xff, n, ctx->stream));                         // .cpp:573
             SVX_TRY(svx_cost_eval_band(ctx, cL, cR, R, Cc, pts, n_hg, disparities, costs, band, prm->maxDisp));
-        else
-            SVX_TRY(svx_cost_eval(ctx, cL, cR, R, Cc, pts, n_hg, disparities, costs));                  // .cpp:574
-        SVX_TRY(svx_refine(ctx, pts, n_hg, disparities, costs, R, Cc, t_low, t_high, occ, final_disp, final_costs,
-                           conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c));                       // .cpp:575-576
+            SVX_TRY(svx_refine(ctx, pts, n_hg, disparities, costs, R, Cc, t_low, t_high, occ, final_disp, final_costs,
+                               conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c));
+        } else                                                                                          // .cpp:573-576: the costs go from the evaluation
+            SVX_TRY(svx_cost_eval_refine(ctx, cL, cR, pts, n_hg, disparities, R, Cc, t_low, t_high, occ, final_disp, final_costs,     // straight into the refinement
+                                         conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c));
         clk.mark(7);
         if (iter != prm->nIters) {                                                                      // .cpp:616-621
             const int gw = Cc / (int)occ + 1, gh = R / (int)occ + 1;

@@ -261,10 +261,15 @@ SVX_API int svx_cost_eval_band(svx_ctx *ctx, const uint32_t *census_left, const 
 // the highest cost above tHigh (invalid match), earliest point first; that is
 // the minimum of the keys below, found with a segmented wavefront scan over
 // runs of equal cells and one 64-bit atomic per run.
+// EVAL: the point's cost is worked out here, as cost_eval_kernel works it out (a10: the prior's own disparity, the right pixel
+// at column 2 or beyond, t_high otherwise), instead of being read from a cost map: svx_high_perf_stereo's form, which needs
+// neither the map nor the launch that fills it.
+template <bool EVAL>
 __global__ __launch_bounds__(256) void refine_points_kernel(const int32_t *__restrict__ pts_xy, int n_pts, const float *__restrict__ disp,
                                                             const int8_t *__restrict__ costs, int rows, int cols, int t_low, int t_high,
                                                             int grid_size, int grid_w, float *__restrict__ final_disp, int8_t *__restrict__ final_costs,
-                                                            unsigned long long *__restrict__ conf_key, unsigned long long *__restrict__ inv_key) {
+                                                            unsigned long long *__restrict__ conf_key, unsigned long long *__restrict__ inv_key,
+                                                            const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long ck = ~0ull, ik = ~0ull;
     int cell = -1;
@@ -274,7 +279,11 @@ __global__ __launch_bounds__(256) void refine_points_kernel(const int32_t *__res
         if (u >= 0 && u < cols && v >= 0 && v < rows) {
             const long o = (long)v * cols + u;
             const float d = disp[o];
-            const int mc = costs[o];
+            int mc;
+            if (EVAL) {
+                const int xr = u - (int)floor((double)d + 0.5);
+                mc = xr < 2 ? t_high : (int)(int8_t)popc32(cl[o] ^ ld_guard_u32(cr, (long)rows * cols, (long)v * cols + xr));
+            } else mc = costs[o];
             if (mc < (int)(uint8_t)final_costs[o]) { final_disp[o] = d; final_costs[o] = (int8_t)mc; }
             cell = (v / grid_size) * grid_w + (u / grid_size);
             if (mc < t_low) ck = ((unsigned long long)(unsigned)(mc + 128) << 32) | (unsigned)p;
@@ -302,8 +311,9 @@ __global__ __launch_bounds__(256) void refine_points_kernel(const int32_t *__res
     }
 }
 
+// (a winner's cost is in its key: no cost map is read)
 __global__ __launch_bounds__(256) void refine_cells_kernel(const int32_t *__restrict__ pts_xy, const float *__restrict__ disp,
-                                                           const int8_t *__restrict__ costs, int cols, int t_low, int t_high, int n_cells,
+                                                           int cols, int t_low, int t_high, int n_cells,
                                                            const unsigned long long *__restrict__ conf_key, const unsigned long long *__restrict__ inv_key,
                                                            int32_t *conf_x, int32_t *conf_y, float *conf_d, int8_t *conf_c,
                                                            int32_t *inv_x, int32_t *inv_y, int8_t *inv_c) {
@@ -314,14 +324,51 @@ __global__ __launch_bounds__(256) void refine_cells_kernel(const int32_t *__rest
     else {
         const unsigned p = (unsigned)(ck & 0xffffffffu);
         const int u = pts_xy[2 * p], v = pts_xy[2 * p + 1];
-        conf_x[c] = u; conf_y[c] = v; conf_d[c] = disp[(long)v * cols + u]; conf_c[c] = costs[(long)v * cols + u];
+        conf_x[c] = u; conf_y[c] = v; conf_d[c] = disp[(long)v * cols + u]; conf_c[c] = (int8_t)((int)(ck >> 32) - 128);
     }
     if (ik == ~0ull) { inv_x[c] = 0; inv_y[c] = 0; inv_c[c] = (int8_t)t_high; }
     else {
         const unsigned p = (unsigned)(ik & 0xffffffffu);
         const int u = pts_xy[2 * p], v = pts_xy[2 * p + 1];
-        inv_x[c] = u; inv_y[c] = v; inv_c[c] = costs[(long)v * cols + u];
+        inv_x[c] = u; inv_y[c] = v; inv_c[c] = (int8_t)(127 - (int)(ik >> 32));
     }
+}
+
+// a11 on a cost map (costs != nullptr), or a10 + a11 in one pass over the points (costs == nullptr: census images given)
+static int refine_impl(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, const int32_t *pts_xy, int n_pts,
+                       const float *disparities, const int8_t *costs, int rows, int cols, int t_low, int t_high, unsigned occ_grid_size,
+                       float *final_disparities, int8_t *final_costs, int32_t *conf_x, int32_t *conf_y, float *conf_d, int8_t *conf_c,
+                       int32_t *inv_x, int32_t *inv_y, int8_t *inv_c, const char *who) {
+    SVX_REQUIRE(ctx, disparities && final_disparities && final_costs, SVX_ERR_INVALID_ARG, "svx_refine: null image pointer");
+    SVX_REQUIRE(ctx, conf_x && conf_y && conf_d && conf_c && inv_x && inv_y && inv_c, SVX_ERR_INVALID_ARG, "svx_refine: null grid pointer");
+    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_refine: empty image");
+    SVX_REQUIRE(ctx, occ_grid_size >= 1 && occ_grid_size <= 0x7fffffffu, SVX_ERR_INVALID_ARG, "svx_refine: occ_grid_size must be >= 1");
+    SVX_REQUIRE(ctx, n_pts >= 0, SVX_ERR_INVALID_ARG, "svx_refine: negative point count");
+    SVX_REQUIRE(ctx, n_pts == 0 || pts_xy, SVX_ERR_INVALID_ARG, "svx_refine: null point list");
+    SVX_REQUIRE(ctx, t_low >= -128 && t_low <= 127 && t_high >= -128 && t_high <= 127, SVX_ERR_INVALID_ARG, "svx_refine: thresholds must fit a signed char");
+    (void)who;
+    const int g = (int)occ_grid_size;
+    const int gw = cols / g + 1, gh = rows / g + 1;
+    const long n_cells = (long)gw * gh;
+    SVX_REQUIRE(ctx, n_cells <= 0x7fffffff, SVX_ERR_UNSUPPORTED, "svx_refine: grid too large");
+    void *ws;
+    int rc = svx_ws_reserve(ctx, 2 * sizeof(unsigned long long) * (size_t)n_cells, &ws);
+    if (rc) return rc;
+    unsigned long long *ck = (unsigned long long *)ws, *ik = ck + n_cells;
+    SVX_HIP(ctx, hipMemsetAsync(ws, 0xff, 2 * sizeof(unsigned long long) * (size_t)n_cells, ctx->stream));
+    if (n_pts > 0) {
+        if (costs)
+            refine_points_kernel<false><<<svx_cdiv(n_pts, 256), 256, 0, ctx->stream>>>(pts_xy, n_pts, disparities, costs, rows, cols, t_low, t_high, g, gw,
+                                                                                      final_disparities, final_costs, ck, ik, nullptr, nullptr);
+        else
+            refine_points_kernel<true><<<svx_cdiv(n_pts, 256), 256, 0, ctx->stream>>>(pts_xy, n_pts, disparities, nullptr, rows, cols, t_low, t_high, g, gw,
+                                                                                     final_disparities, final_costs, ck, ik, census_left, census_right);
+        SVX_LAUNCH_CHECK(ctx, "refine_points_kernel");
+    }
+    refine_cells_kernel<<<svx_cdiv(n_cells, 256), 256, 0, ctx->stream>>>(pts_xy, disparities, cols, t_low, t_high, (int)n_cells, ck, ik,
+                                                                        conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c);
+    SVX_LAUNCH_CHECK(ctx, "refine_cells_kernel");
+    return SVX_OK;
 }
 
 SVX_API int svx_refine(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const float *disparities, const int8_t *costs,
@@ -331,31 +378,19 @@ SVX_API int svx_refine(svx_ctx *ctx, const int32_t *pts_xy, int n_pts, const flo
                        int32_t *inv_x, int32_t *inv_y, int8_t *inv_c) {
     int rc = svx_enter(ctx);
     if (rc) return rc;
-    SVX_REQUIRE(ctx, disparities && costs && final_disparities && final_costs, SVX_ERR_INVALID_ARG, "svx_refine: null image pointer");
-    SVX_REQUIRE(ctx, conf_x && conf_y && conf_d && conf_c && inv_x && inv_y && inv_c, SVX_ERR_INVALID_ARG, "svx_refine: null grid pointer");
-    SVX_REQUIRE(ctx, rows > 0 && cols > 0, SVX_ERR_EMPTY, "svx_refine: empty image");
-    SVX_REQUIRE(ctx, occ_grid_size >= 1 && occ_grid_size <= 0x7fffffffu, SVX_ERR_INVALID_ARG, "svx_refine: occ_grid_size must be >= 1");
-    SVX_REQUIRE(ctx, n_pts >= 0, SVX_ERR_INVALID_ARG, "svx_refine: negative point count");
-    SVX_REQUIRE(ctx, n_pts == 0 || pts_xy, SVX_ERR_INVALID_ARG, "svx_refine: null point list");
-    SVX_REQUIRE(ctx, t_low >= -128 && t_low <= 127 && t_high >= -128 && t_high <= 127, SVX_ERR_INVALID_ARG, "svx_refine: thresholds must fit a signed char");
-    const int g = (int)occ_grid_size;
-    const int gw = cols / g + 1, gh = rows / g + 1;
-    const long n_cells = (long)gw * gh;
-    SVX_REQUIRE(ctx, n_cells <= 0x7fffffff, SVX_ERR_UNSUPPORTED, "svx_refine: grid too large");
-    void *ws;
-    rc = svx_ws_reserve(ctx, 2 * sizeof(unsigned long long) * (size_t)n_cells, &ws);
-    if (rc) return rc;
-    unsigned long long *ck = (unsigned long long *)ws, *ik = ck + n_cells;
-    SVX_HIP(ctx, hipMemsetAsync(ws, 0xff, 2 * sizeof(unsigned long long) * (size_t)n_cells, ctx->stream));
-    if (n_pts > 0) {
-        refine_points_kernel<<<svx_cdiv(n_pts, 256), 256, 0, ctx->stream>>>(pts_xy, n_pts, disparities, costs, rows, cols, t_low, t_high, g, gw,
-                                                                           final_disparities, final_costs, ck, ik);
-        SVX_LAUNCH_CHECK(ctx, "refine_points_kernel");
-    }
-    refine_cells_kernel<<<svx_cdiv(n_cells, 256), 256, 0, ctx->stream>>>(pts_xy, disparities, costs, cols, t_low, t_high, (int)n_cells, ck, ik,
-                                                                        conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c);
-    SVX_LAUNCH_CHECK(ctx, "refine_cells_kernel");
-    return SVX_OK;
+    SVX_REQUIRE(ctx, costs != nullptr, SVX_ERR_INVALID_ARG, "svx_refine: null image pointer");
+    return refine_impl(ctx, nullptr, nullptr, pts_xy, n_pts, disparities, costs, rows, cols, t_low, t_high, occ_grid_size, final_disparities, final_costs,
+                       conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c, "svx_refine");
+}
+
+// svx_cost_eval followed by svx_refine without the cost map between them (what svx_high_perf_stereo runs per iteration).
+int svx_cost_eval_refine(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, const int32_t *pts_xy, int n_pts,
+                         const float *disparities, int rows, int cols, int t_low, int t_high, unsigned occ_grid_size,
+                         float *final_disparities, int8_t *final_costs, int32_t *conf_x, int32_t *conf_y, float *conf_d, int8_t *conf_c,
+                         int32_t *inv_x, int32_t *inv_y, int8_t *inv_c) {
+    SVX_REQUIRE(ctx, census_left && census_right, SVX_ERR_INVALID_ARG, "svx_cost_eval: null image pointer");
+    return refine_impl(ctx, census_left, census_right, pts_xy, n_pts, disparities, nullptr, rows, cols, t_low, t_high, occ_grid_size, final_disparities,
+                       final_costs, conf_x, conf_y, conf_d, conf_c, inv_x, inv_y, inv_c, "svx_cost_eval_refine");
 }
 
 // --------------------------------------------------------------- a12 -----
