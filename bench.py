@@ -124,9 +124,16 @@ def cpu_baseline_9x7(left, right, D, n_frames_work, lr, lr_threshold):
     }, want, nrows
 
 
-def mx_passes(D):
-    """Launches of the matrix-core search for D disparities (svx_dense_mx.hip, mx_plan)."""
-    return 1 if D <= 128 else 1 + -(-(D - 128) // 160)
+def mx_plan(D, words=2, wide=-1):
+    """(tiles per wavefront, launches) of the matrix-core search for D disparities (svx_dense_mx.hip, mx_plan); wide: the
+    context's SVX_OPT_MX_WIDE_TILES."""
+    if D <= 64:
+        return 3, 1
+    if D <= 128:
+        return 5, 1
+    if D <= 256 and words == 2 and (wide == 1 or (wide < 0 and D > 224)):
+        return 9, 1
+    return 5, 1 + -(-(D - 128) // 160)
 
 
 def host_threads():
@@ -354,7 +361,8 @@ def main():
         kernel_name = S.dense_kernel_name(rows, cols, words, D, both_views, ctx)
         on_matrix_cores = kernel_name == "dense_wta_mx_kernel"
         if on_matrix_cores:      # one key per right column a workgroup (four 32-column blocks) covers, per output row and pass of 128 disparities
-            part_bytes = 4.0 * 32 * (4 + (3 if D <= 64 else 5) - 1) * mx_passes(D) * F * (rows - 4) * -(-((cols - 4 + 31) // 32) // 4) if both_views else 0.0
+            plan_tiles, plan_passes = mx_plan(D, words, ctx.get_option(S.OPT_MX_WIDE_TILES))
+            part_bytes = 4.0 * 32 * (4 + plan_tiles - 1) * plan_passes * F * (rows - 4) * -(-((cols - 4 + 31) // 32) // 4) if both_views else 0.0
         else:
             part_bytes = 4.0 * 80 * F * (rows - 4) * ((cols - 4 + 15) // 16) * ((D + 63) // 64) if both_views else 0.0
         kernel_io_bytes = float(rows * cols * F * (2 * 4 * words + 4)) + part_bytes     # what this kernel itself must move
@@ -405,9 +413,9 @@ def main():
             # algorithmic work = per pix*disp one 5-column dot product over the descriptor bits for the census row that enters the
             # 5-row window and one for the row that leaves it = 2 * 5 * 64 multiply-adds = 1280 flop with 64-bit descriptors.  The vector-popcount
             # pricing used for the sweep kernel (2 lane-instructions per descriptor word and pix*disp) stays beside it.
-            tiles, passes = (3 if D <= 64 else 5), mx_passes(D)      # more than 128 disparities: passes whose five tiles lie side by side (160 right columns each)
+            tiles, passes = mx_plan(D, words, ctx.get_option(S.OPT_MX_WIDE_TILES))      # more than 128 disparities: passes whose five tiles lie side by side (160 right columns each), or nine tiles in one
             # strips as svx_launch_mx_sweep chooses them (a strip's first five rows have nothing leaving the window yet)
-            slots = torch.cuda.get_device_properties(dev).multi_processor_count * 2     # workgroups of four wavefronts, two per CU
+            slots = torch.cuda.get_device_properties(dev).multi_processor_count * (2 if tiles <= 5 else 1)     # workgroups of four wavefronts, two per CU (one with nine tiles)
             per_strip = -(-((cols - 4 + 31) // 32) // 4) * F
             cost = lambda k: -(-per_strip * k // slots) * (-(-(rows - 4) // k) + 6)
             k_best = min(range(1, min(16, rows - 4) + 1), key=lambda k: (cost(k), k))

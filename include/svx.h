@@ -72,7 +72,8 @@ int svx_synchronize(svx_ctx *ctx);
  *   SVX_OPT_STAGE_TIMES      (SVX_STAGE_TIMES)     1 = svx_high_perf_stereo synchronises at its stage marks and fills
  *                                                  svx_pipeline_stage_times (default 0: no synchronisation, times 0)
  *   SVX_OPT_MX_WIDE_TILES    (SVX_MX_WIDE_TILES)   1 = 129..256 disparities in one pass of the nine-tile matrix-core kernel
- *                                                  instead of two passes of the five-tile one (default 0)
+ *                                                  instead of two passes of the five-tile one, 0 = never; default -1: from 225
+ *                                                  disparities on, where the two passes compute nine tiles as well
  *   SVX_OPT_MESH_ON_DEVICE   (SVX_MESH_ON_DEVICE)  0 = svx_high_perf_stereo triangulates its support points on the host
  *                                                  (svx_mesh_*); default 1 = on the device (svx_mesh_plane_prior_device);
  *                                                  the triangles are the same

@@ -915,7 +915,7 @@ bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX
 
 // Tiles per wavefront and launches per search: up to 64 / 128 disparities three / five tiles in one pass; wider ranges in
 // passes of five tiles (two wavefronts per SIMD; nine tiles in one pass leave room for one, which is slower per disparity),
-// unless SVX_OPT_MX_WIDE_TILES asks for the nine-tile kernel at up to 256.  The passes' tiles lie side by side: pass p holds the
+// except that 225..256 disparities take the nine-tile kernel (SVX_OPT_MX_WIDE_TILES: 1 = from 129 on, 0 = never).  The passes' tiles lie side by side: pass p holds the
 // right columns xl0 - 128 - 160 p .. xl0 + 31 - 160 p, so only the first pass (d < 0) and the last (d >= max_disp) compute pairs
 // outside the band, where passes of 128 disparities each would compute a half-empty first and last tile per pass: left column
 // xl0 + m has reached disparity 128 + 160 p + m after pass p, which makes 1 + ceil((max_disp - 128) / 160) passes (256: 9 tiles
@@ -924,7 +924,11 @@ struct MxPlan { int tiles, passes; };
 static MxPlan mx_plan(const svx_ctx *ctx, int max_disp, int words = 2) {
     if (max_disp <= 64) return {3, 1};
     if (max_disp <= 128) return {5, 1};
-    if (max_disp <= 256 && words == 2 && svx_opt(ctx, SVX_OPT_MX_WIDE_TILES) == 1) return {9, 1};
+    // 129..256 disparities on two-word descriptors: nine tiles in one pass when the option asks for it (1), and by default (-1)
+    // where the passes would compute nine tiles as well (beyond 224 disparities: one launch, the left operands staged once, 384
+    // instead of 512 partial keys per group and row: 3-4 % per step at 256 on four frame sizes); 0: always passes of five tiles
+    const int wide = svx_opt(ctx, SVX_OPT_MX_WIDE_TILES);
+    if (max_disp <= 256 && words == 2 && (wide == 1 || (wide < 0 && max_disp > 224))) return {9, 1};
     return {5, 1 + (max_disp - 128 + MX_PASS_STEP - 1) / MX_PASS_STEP};
 }
 static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }

@@ -233,13 +233,14 @@ def test_matrix_search_equals_vector_sweep_on_whole_frames(ctx, rows, cols, D, f
         ctx.set_option(S.OPT_MATRIX_CORES, -1)
     ml, mr = ctx.dense_wta_matrix(cl, cr, D)
     ml0, _ = ctx.dense_wta_matrix(cl, cr, D, both=False)
-    if 128 < D <= 256:                      # the one-pass nine-tile kernel beside the two passes of five tiles
-        ctx.set_option(S.OPT_MX_WIDE_TILES, 1)
-        try:
-            nl, nr = ctx.dense_wta_matrix(cl, cr, D)
-        finally:
-            ctx.set_option(S.OPT_MX_WIDE_TILES, 0)
-        assert torch.equal(nl, wl) and torch.equal(nr, wr)
+    if 128 < D <= 256:                      # the one-pass nine-tile kernel and the two passes of five tiles, whichever is the default at D
+        for wide in (1, 0):
+            ctx.set_option(S.OPT_MX_WIDE_TILES, wide)
+            try:
+                nl, nr = ctx.dense_wta_matrix(cl, cr, D)
+            finally:
+                ctx.set_option(S.OPT_MX_WIDE_TILES, -1)
+            assert torch.equal(nl, wl) and torch.equal(nr, wr), wide
     assert torch.equal(ml, wl), (ml != wl).nonzero()[:5].tolist()
     assert torch.equal(ml0, wl), (ml0 != wl).nonzero()[:5].tolist()
     assert torch.equal(mr, wr), (mr != wr).nonzero()[:5].tolist()
@@ -298,7 +299,7 @@ def test_matrix_search_strip_lengths(ctx, strip_rows, D, words):
     assert torch.equal(mr, wr), (mr != wr).nonzero()[:5].tolist()
 
 
-@pytest.mark.parametrize("D", [48, 160])
+@pytest.mark.parametrize("D", [48, 160, 240])
 @pytest.mark.parametrize("words", [1, 2])
 def test_matrix_search_narrowest_frame_on_a_fresh_context(D, words):
     """cols == 36, the narrowest frame the matrix-core search takes: its one workgroup leaves more partial keys per row
