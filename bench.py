@@ -131,9 +131,15 @@ def mx_plan(D, words=2, wide=-1):
         return 3, 1
     if D <= 128:
         return 5, 1
-    if D <= 256 and words == 2 and (wide == 1 or (wide < 0 and D > 224)):
-        return 9, 1
-    return 5, 1 + -(-(D - 128) // 160)
+    passes5 = 1 + -(-(D - 128) // 160)
+    tiles5 = 0
+    for p in range(passes5):
+        beyond = 160 * p + 97 - D
+        tiles5 += 5 - (min(beyond // 32 + 1, 2) if beyond >= 0 else 0)
+    passes9 = 1 if D <= 256 else 1 + -(-(D - 256) // 288)
+    if words == 2 and (wide == 1 or (wide < 0 and passes9 == 1 and 9 <= tiles5)):
+        return 9, passes9
+    return 5, passes5
 
 
 def host_threads():

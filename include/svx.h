@@ -71,9 +71,9 @@ int svx_synchronize(svx_ctx *ctx);
  *   SVX_OPT_MX_STRIP_ROWS    (SVX_MX_STRIP_ROWS)   > 0 forces the output rows per strip of the matrix-core search
  *   SVX_OPT_STAGE_TIMES      (SVX_STAGE_TIMES)     1 = svx_high_perf_stereo synchronises at its stage marks and fills
  *                                                  svx_pipeline_stage_times (default 0: no synchronisation, times 0)
- *   SVX_OPT_MX_WIDE_TILES    (SVX_MX_WIDE_TILES)   1 = 129..256 disparities in one pass of the nine-tile matrix-core kernel
- *                                                  instead of two passes of the five-tile one, 0 = never; default -1: from 225
- *                                                  disparities on, where the two passes compute nine tiles as well
+ *   SVX_OPT_MX_WIDE_TILES    (SVX_MX_WIDE_TILES)   more than 128 disparities on two-word descriptors: 1 = passes of the nine-tile
+ *                                                  matrix-core kernel, 0 = passes of the five-tile one; default -1: nine tiles where
+ *                                                  one pass of them covers the range with no more tiles than passes of five (225..256)
  *   SVX_OPT_MESH_ON_DEVICE   (SVX_MESH_ON_DEVICE)  0 = svx_high_perf_stereo triangulates its support points on the host
  *                                                  (svx_mesh_*); default 1 = on the device (svx_mesh_plane_prior_device);
  *                                                  the triangles are the same
@@ -517,7 +517,7 @@ int svx_dense_kernel_choice(const svx_ctx *ctx, int rows, int cols, int words, i
 /* The search of svx_dense_wta / svx_dense_wta_both on two-word descriptors with the cost values formed on the matrix
  * cores (fp4 dot products of the expanded descriptors; denseCensusStereo/denseCensusStereo.cpp:87-131 generalised as
  * there): identical results.  Covers cols >= 36, rows >= 5, 1 <= max_disp <= 1024 (SVX_ERR_UNSUPPORTED otherwise); more
- * than 128 disparities are searched in passes (160 right columns each, side by side) whose winners' keys are merged.
+ * than 128 disparities are searched in passes (160 or 288 right columns each, side by side) whose winners' keys are merged.
  * disp_right may be NULL (left view only).  Border pixels are written as 0.  Asynchronous. */
 int svx_dense_wta_matrix(svx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int rows, int cols, int n_frames,
                          int max_disp, float *disp_left, float *disp_right);

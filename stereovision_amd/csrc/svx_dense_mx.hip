@@ -42,7 +42,7 @@ constexpr int MX_M = 32;                 // left columns per wavefront
 constexpr int MX_NBUF = 3;               // staged rows in flight: the one being read, the one being written, and one in between (see mx_strip)
 constexpr int MX_KROWS = 3;              // right view: key rows in LDS (the one being written out, the one being filled, and the next one the wavefronts ahead fill)
 constexpr float MX_NO_KEY = -4194304.0f; // below every key, admissible or not
-constexpr int MX_PASS_STEP = 160;        // more than 128 disparities: pass p takes the right columns 160 p further left (all columns of its five tiles, see mx_plan)
+constexpr int mx_pass_step(int tiles) { return 32 * tiles; }   // a range beyond one pass: pass p takes the right columns 32 T p further left (all columns of its T tiles, see mx_plan)
 
 template <int T, int WORDS = 2>
 struct MxGeom {
@@ -869,7 +869,7 @@ __device__ __forceinline__ float svx_mx_right_key(const float *__restrict__ prow
 template <int T>
 __device__ __forceinline__ float svx_mx_right_disparity(const float *__restrict__ prow, long pass_stride, int n_pass, int xr, int cols, int n_groups) {
     float best = svx_mx_right_key<T>(prow, xr, cols, n_groups);
-    for (int p = 1; p < n_pass; ++p) best = fmaxf(best, svx_mx_right_key<T>(prow + p * pass_stride, xr + p * MX_PASS_STEP, cols, n_groups));
+    for (int p = 1; p < n_pass; ++p) best = fmaxf(best, svx_mx_right_key<T>(prow + p * pass_stride, xr + p * mx_pass_step(T), cols, n_groups));
     // right columns 2..4 are admitted by the right view only: each of their pairs started 4096 lower (mx_strip), so the
     // best of them is lifted here (a column without any pair stays far below the threshold of mx_decode)
     return mx_decode(xr < 5 ? best + 4096.0f : best);
@@ -914,22 +914,32 @@ __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp) { return cols >= MX_M + 4 && rows >= 5 && max_disp >= 1 && max_disp <= MX_MAX_DISP; }
 
 // Tiles per wavefront and launches per search: up to 64 / 128 disparities three / five tiles in one pass; wider ranges in
-// passes of five tiles (two wavefronts per SIMD; nine tiles in one pass leave room for one, which is slower per disparity),
-// except that 225..256 disparities take the nine-tile kernel (SVX_OPT_MX_WIDE_TILES: 1 = from 129 on, 0 = never).  The passes' tiles lie side by side: pass p holds the
-// right columns xl0 - 128 - 160 p .. xl0 + 31 - 160 p, so only the first pass (d < 0) and the last (d >= max_disp) compute pairs
-// outside the band, where passes of 128 disparities each would compute a half-empty first and last tile per pass: left column
-// xl0 + m has reached disparity 128 + 160 p + m after pass p, which makes 1 + ceil((max_disp - 128) / 160) passes (256: 9 tiles
-// instead of 10; 512: 18 instead of 20, three of the last pass's five being skipped or dead; 1024: 34 instead of 40).
+// passes of T = five or nine tiles (mx_plan chooses).  The passes' tiles lie side by side: pass p holds the right columns
+// xl0 - 32 (T - 1) - 32 T p .. xl0 + 31 - 32 T p, so only the first pass (d < 0) and the last (d >= max_disp) compute pairs
+// outside the band, where passes of 32 (T - 1) disparities each would compute a half-empty first and last tile per pass: left
+// column xl0 + m has reached disparity 32 (T - 1) + 32 T p + m after pass p, which makes 1 + ceil((max_disp - 32 (T - 1)) / 32 T)
+// passes (five tiles, 256: 9 tiles instead of 10; 512: 18 instead of 20, three of the last pass's five being skipped or dead;
+// 1024: 34 instead of 40).
 struct MxPlan { int tiles, passes; };
 static MxPlan mx_plan(const svx_ctx *ctx, int max_disp, int words = 2) {
     if (max_disp <= 64) return {3, 1};
     if (max_disp <= 128) return {5, 1};
-    // 129..256 disparities on two-word descriptors: nine tiles in one pass when the option asks for it (1), and by default (-1)
-    // where the passes would compute nine tiles as well (beyond 224 disparities: one launch, the left operands staged once, 384
-    // instead of 512 partial keys per group and row: 3-4 % per step at 256 on four frame sizes); 0: always passes of five tiles
+    // More than 128 disparities: passes of five tiles (two wavefronts per SIMD; the last pass's leading tiles whose disparities all
+    // lie beyond the range are not computed, at most two of five) or, on two-word descriptors, passes of nine (one wavefront per
+    // SIMD, every tile computed): fewer launches, the left operands staged less often, fewer partial keys for the check to read.
+    // SVX_OPT_MX_WIDE_TILES: 1 = nine tiles wherever they apply, 0 = never, -1 (default) = where one pass of nine computes no
+    // more tiles than the passes of five (225..256 disparities: 3-4 % per step on four frame sizes).  Several passes of nine
+    // measured within 1 % of the passes of five where the tile counts are equal (449..544, 737..832) and slower elsewhere.
+    const int passes5 = 1 + (max_disp - 128 + mx_pass_step(5) - 1) / mx_pass_step(5);
+    int tiles5 = 0;
+    for (int p = 0; p < passes5; ++p) {
+        const int beyond = p * mx_pass_step(5) + 97 - max_disp;
+        tiles5 += 5 - (beyond >= 0 ? (beyond / 32 + 1 < 2 ? beyond / 32 + 1 : 2) : 0);
+    }
+    const int passes9 = max_disp <= 256 ? 1 : 1 + (max_disp - 256 + mx_pass_step(9) - 1) / mx_pass_step(9);
     const int wide = svx_opt(ctx, SVX_OPT_MX_WIDE_TILES);
-    if (max_disp <= 256 && words == 2 && (wide == 1 || (wide < 0 && max_disp > 224))) return {9, 1};
-    return {5, 1 + (max_disp - 128 + MX_PASS_STEP - 1) / MX_PASS_STEP};
+    if (words == 2 && (wide == 1 || (wide < 0 && passes9 == 1 && 9 <= tiles5))) return {9, passes9};
+    return {5, passes5};
 }
 static int mx_xblocks(int cols) { return (cols - 4 + MX_M - 1) / MX_M; }
 static int mx_groups(int cols) { return (mx_xblocks(cols) + MX_W - 1) / MX_W; }                 // workgroups along x
@@ -969,7 +979,7 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     const int nb = mx_xblocks(cols);
     const size_t pass_words = (size_t)n_frames * rows * n_groups * mx_keys_per_group(T);
     for (int p = 0; p < plan.passes; ++p) {
-        const int d_base = p * MX_PASS_STEP, flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes ? 2 : 0);
+        const int d_base = p * mx_pass_step(T), flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes ? 2 : 0);
         const int wb = p + 1 == plan.passes ? write_border : 0;
         float *part = partial ? partial + p * pass_words : nullptr;
 #define MX_LAUNCH(TT, WW, BB, PART) dense_wta_mx_kernel<TT, WW, BB><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, PART)

@@ -216,7 +216,8 @@ def test_lr_check_values_that_are_no_disparity(ctx):
 
 
 @pytest.mark.parametrize("rows,cols,D,frames", [(375, 1242, 64, 2), (368, 1232, 128, 2), (1072, 1920, 200, 1), (540, 960, 256, 1),
-                                                 (300, 2000, 33, 1), (300, 2000, 65, 1), (300, 2000, 129, 1), (270, 1920, 512, 1), (200, 1600, 300, 2)])
+                                                 (300, 2000, 33, 1), (300, 2000, 65, 1), (300, 2000, 129, 1), (270, 1920, 512, 1), (200, 1600, 300, 2),
+                                                 (120, 2400, 700, 1), (90, 2600, 1024, 1)])
 def test_matrix_search_equals_vector_sweep_on_whole_frames(ctx, rows, cols, D, frames):
     """Every tile count of the matrix-core search (3, 5 and 9 tiles: up to 64, 128 and 256 disparities), both views, on
     whole large frames against the vector sweep (itself checked against the oracle on bands of such frames): a build of
@@ -233,7 +234,7 @@ def test_matrix_search_equals_vector_sweep_on_whole_frames(ctx, rows, cols, D, f
         ctx.set_option(S.OPT_MATRIX_CORES, -1)
     ml, mr = ctx.dense_wta_matrix(cl, cr, D)
     ml0, _ = ctx.dense_wta_matrix(cl, cr, D, both=False)
-    if 128 < D <= 256:                      # the one-pass nine-tile kernel and the two passes of five tiles, whichever is the default at D
+    if D > 128:                             # passes of nine tiles and passes of five, whichever is the default at D
         for wide in (1, 0):
             ctx.set_option(S.OPT_MX_WIDE_TILES, wide)
             try:

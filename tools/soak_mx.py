@@ -1,5 +1,5 @@
 """Random sizes through the matrix-core search (left view, both views, fused left-right entry) against the vector sweep:
-widths that leave idle wavefronts or a shifted last x-block, short strips, every tile count, one- and two-word descriptors.
+widths that leave idle wavefronts or a shifted last x-block, short strips, every tile count and pass width, one- and two-word descriptors.
 Measurement aid (run on the GPU box): tools/soak_mx.py [cases] [seed]"""
 import os
 import sys
@@ -23,6 +23,7 @@ for case in range(n_cases):
     words = int(rng.integers(1, 3))
     frames = int(rng.integers(1, 4))
     strip = int(rng.choice([0, 0, rng.integers(1, 12)]))
+    wide = int(rng.choice([-1, -1, 0, 1]))
     ls, rs = synth.stereo_batch(rows, cols, min(D, max(cols // 2, 1)), frames, seed0=1000 + case)
     dl, dr = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
     cl, cr = (ctx.census9x7(dl), ctx.census9x7(dr)) if words == 2 else (ctx.census5x5(dl), ctx.census5x5(dr))
@@ -31,6 +32,7 @@ for case in range(n_cases):
     wr = ctx.dense_wta(cl, cr, D, S.VIEW_RIGHT, words)
     ctx.set_option(S.OPT_MATRIX_CORES, -1)
     ctx.set_option(S.OPT_MX_STRIP_ROWS, strip)
+    ctx.set_option(S.OPT_MX_WIDE_TILES, wide)
     ml, mr = ctx.dense_wta_both(cl, cr, D, words)
     ml0 = ctx.dense_wta(cl, cr, D, S.VIEW_LEFT, words)
     ok = torch.equal(ml, wl) and torch.equal(mr, wr) and torch.equal(ml0, wl)
@@ -39,10 +41,11 @@ for case in range(n_cases):
         want = ctx.lr_check(wl.clone(), wr, 1.0)
         ok = ok and torch.equal(fused, want)
     ctx.set_option(S.OPT_MX_STRIP_ROWS, 0)
+    ctx.set_option(S.OPT_MX_WIDE_TILES, -1)
     if not ok:
         bad += 1
-        print("MISMATCH rows=%d cols=%d D=%d words=%d frames=%d strip=%d: left %d, left-only %d, right %d" % (
-            rows, cols, D, words, frames, strip, int((ml != wl).sum()), int((ml0 != wl).sum()), int((mr != wr).sum())), flush=True)
+        print("MISMATCH rows=%d cols=%d D=%d words=%d frames=%d strip=%d wide=%d: left %d, left-only %d, right %d" % (
+            rows, cols, D, words, frames, strip, wide, int((ml != wl).sum()), int((ml0 != wl).sum()), int((mr != wr).sum())), flush=True)
     if case % 20 == 19:
         print("%d cases, %d mismatches" % (case + 1, bad), flush=True)
 print("done: %d cases, %d mismatches" % (n_cases, bad))
