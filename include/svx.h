@@ -77,8 +77,9 @@ int svx_synchronize(svx_ctx *ctx);
  *   SVX_OPT_MESH_ON_DEVICE   (SVX_MESH_ON_DEVICE)  0 = svx_high_perf_stereo triangulates its support points on the host
  *                                                  (svx_mesh_*); default 1 = on the device (svx_mesh_plane_prior_device);
  *                                                  the triangles are the same
- *   SVX_OPT_SUBPIXEL_TILES   (SVX_SUBPIXEL_TILES)  0 = the sub-pixel step reads every descriptor from memory; default 1 = the left
- *                                                  descriptors of a block of pixels are staged in LDS
+ *   SVX_OPT_SUBPIXEL_TILES   (SVX_SUBPIXEL_TILES)  0 = the sub-pixel step reads every descriptor from memory; 1 = the left
+ *                                                  descriptors of a block of pixels are staged in LDS; default 2 = the right ones
+ *                                                  too, up to 252 disparities (beyond: as 1)
  * The one option that changes results:
  *   SVX_OPT_PRIOR_BAND_RADIUS (SVX_PRIOR_BAND_RADIUS) radius of svx_high_perf_stereo's search around the plane prior
  *                                                  (svx_cost_eval_band); default 0 = the reference's single disparity */

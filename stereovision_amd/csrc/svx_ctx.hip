@@ -150,7 +150,7 @@ static const struct { int builtin; const char *env; } svx_option_table[SVX_OPT_C
     /* SVX_OPT_PRIOR_BAND_RADIUS */ {0, "SVX_PRIOR_BAND_RADIUS"},
     /* SVX_OPT_MX_WIDE_TILES */ {-1, "SVX_MX_WIDE_TILES"},
     /* SVX_OPT_MESH_ON_DEVICE */ {1, "SVX_MESH_ON_DEVICE"},
-    /* SVX_OPT_SUBPIXEL_TILES */ {1, "SVX_SUBPIXEL_TILES"},
+    /* SVX_OPT_SUBPIXEL_TILES */ {2, "SVX_SUBPIXEL_TILES"},
 };
 
 int svx_option_default(int option) {

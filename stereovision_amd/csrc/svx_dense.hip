@@ -1160,7 +1160,137 @@ __global__ __launch_bounds__(256) void subpixel_tile_kernel(const uint32_t *__re
     }
 }
 
+// acc + popcount(v) as the one instruction it is (left to itself the compiler sums the counts of a long chain in a tree of
+// three-way additions, a quarter more instructions).
+__device__ __forceinline__ int popc_acc(uint32_t v, int acc) {
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(acc));
+    return r;
+}
+
+// Both neighbourhoods of a block in LDS (8 output rows x 256 columns, 1024 threads: four row groups of 256): the right descriptors
+// a pixel needs lie at the columns x - d - 3 .. x - d + 3 of five rows, so a block's pixels with disparities up to d_cap read them
+// from the columns x0 - d_cap - 3 .. x0 + 258 of its 12 rows, staged once (about 4 descriptors a pixel, every thread's loads in
+// flight together) instead of gathered 35 at a time through the vector cache, where neighbouring pixels of one disparity fetch the
+// same descriptors seven times over.  Lanes of one disparity read consecutive LDS words (no bank conflict); a pixel whose disparity
+// exceeds d_cap gathers from memory as before.  RCH = 256-column chunks of the right tile.  Two blocks a CU need 64 registers a
+// thread at most and 80 KiB of LDS a block: two chunks, disparities up to 250.  Same arithmetic, same results.
+constexpr int SPX2_ROWS = 8, SPX2_GROUPS = 4, SPX2_CHUNKS = 2, SPX2_DCAP = 256 * SPX2_CHUNKS - (SPX_W + 6);
+template <int WORDS, int RCH>
+__global__ __launch_bounds__(256 * SPX2_GROUPS, 8) void subpixel_pair_tile_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
+                                                                                int rows, int cols, int max_disp, int d_cap, float *__restrict__ disp_all) {
+    typedef typename std::conditional<WORDS == 2, uint2, uint32_t>::type desc_t;
+    extern __shared__ __align__(16) unsigned char spx_lds[];
+    constexpr int TROWS = SPX2_ROWS + 4, RPT = TROWS / SPX2_GROUPS;           // tile rows, and tile rows a row group stages
+    desc_t *ltile = reinterpret_cast<desc_t *>(spx_lds);
+    desc_t *rtile = ltile + TROWS * SPX_PITCH;
+    const int r_pitch = SPX_W + 6 + d_cap;
+    const long n = (long)rows * cols;
+    const desc_t *cl = reinterpret_cast<const desc_t *>(cl_all) + (long)blockIdx.z * n;
+    const desc_t *cr = reinterpret_cast<const desc_t *>(cr_all) + (long)blockIdx.z * n;
+    float *disp = disp_all + (long)blockIdx.z * n;
+    const int col = threadIdx.x & 255, grp = threadIdx.x >> 8;
+    const int x0 = blockIdx.x * SPX_W, y0 = 2 + blockIdx.y * SPX2_ROWS;      // first output pixel of the block (rows 2 .. rows-3 have outputs)
+    const int rx0 = x0 - d_cap - 3;                                          // image column of the right tile's column 0
+    {
+        desc_t lv[RPT][2], rv[RPT][RCH];                                      // (clamped pixels are only read by pixels without an output)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const long grow = (long)min(y0 - 2 + grp + SPX2_GROUPS * r, rows - 1) * cols;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (col + 256 * c < SPX_PITCH) lv[r][c] = cl[grow + min(max(x0 - 2 + col + 256 * c, 0), cols - 1)];
+#pragma unroll
+            for (int c = 0; c < RCH; ++c)
+                if (col + 256 * c < r_pitch) rv[r][c] = cr[grow + min(max(rx0 + col + 256 * c, 0), cols - 1)];
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int ty = grp + SPX2_GROUPS * r;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (col + 256 * c < SPX_PITCH) ltile[ty * SPX_PITCH + col + 256 * c] = lv[r][c];
+#pragma unroll
+            for (int c = 0; c < RCH; ++c)
+                if (col + 256 * c < r_pitch) rtile[ty * r_pitch + col + 256 * c] = rv[r][c];
+        }
+    }
+    __syncthreads();
+    const int x = x0 + col;
+    if (x < 2 || x >= cols - 2) return;
+#pragma unroll 1
+    for (int j = grp; j < SPX2_ROWS; j += SPX2_GROUPS) {
+        const int y = y0 + j;
+        if (y >= rows - 2) break;
+        const float f = disp[(long)y * cols + x];
+        if (!(f >= 1.0f) || !(f < (float)max_disp)) continue;                     // also NaN and values no int can hold
+        const int d = (int)f;
+        if ((float)d != f || d + 1 > max_disp - 1 || x - (d + 1) < 5) continue;
+        int c0 = 0, c1 = 0, c2 = 0;
+        if (d <= d_cap) {
+            const desc_t *lbase = ltile + j * SPX_PITCH + col;                    // window column -2 of window row -2
+            const desc_t *rbase = rtile + j * r_pitch + (x - d - 3 - rx0);        // right column x - d - 3 of window row -2
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                desc_t rw[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) rw[k] = rbase[m * r_pitch + k];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const desc_t lw = lbase[m * SPX_PITCH + k];
+                    if constexpr (WORDS == 2) {
+                        c0 = popc_acc(lw.y ^ rw[k + 2].y, popc_acc(lw.x ^ rw[k + 2].x, c0));      // disparity d-1: right column x-d+1
+                        c1 = popc_acc(lw.y ^ rw[k + 1].y, popc_acc(lw.x ^ rw[k + 1].x, c1));
+                        c2 = popc_acc(lw.y ^ rw[k].y, popc_acc(lw.x ^ rw[k].x, c2));              // disparity d+1
+                    } else {
+                        c0 = popc_acc(lw ^ rw[k + 2], c0);
+                        c1 = popc_acc(lw ^ rw[k + 1], c1);
+                        c2 = popc_acc(lw ^ rw[k], c2);
+                    }
+                }
+            }
+        } else {
+            const uint32_t *crw = cr_all + (long)blockIdx.z * n * WORDS;
+#pragma unroll
+            for (int m = -2; m <= 2; ++m) {
+                const desc_t *lrow = ltile + (j + 2 + m) * SPX_PITCH + col + 2;
+                const uint32_t *rrow = crw + ((long)(y + m) * cols + x - d) * WORDS;
+#pragma unroll
+                for (int k = -2; k <= 2; ++k) {
+                    const desc_t lw = lrow[k];
+#pragma unroll
+                    for (int w = 0; w < WORDS; ++w) {
+                        uint32_t l;
+                        if constexpr (WORDS == 2) l = w ? lw.y : lw.x; else l = lw;
+                        c0 += popc32(l ^ rrow[(k + 1) * WORDS + w]);
+                        c1 += popc32(l ^ rrow[k * WORDS + w]);
+                        c2 += popc32(l ^ rrow[(k - 1) * WORDS + w]);
+                    }
+                }
+            }
+        }
+        const int den = c0 - 2 * c1 + c2;
+        if (den > 0) disp[(long)y * cols + x] = (float)d + __fdiv_rn((float)(c0 - c2), (float)(2 * den));
+    }
+}
+
+template <int WORDS>
+static int launch_subpixel_pair_tiles(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp, float *disparity) {
+    const int d_cap = max_disp - 2 < 0 ? 0 : max_disp - 2 < SPX2_DCAP ? max_disp - 2 : SPX2_DCAP;
+    const size_t lds = (size_t)(SPX2_ROWS + 4) * 4 * WORDS * (size_t)(SPX_PITCH + SPX_W + 6 + d_cap);
+    const dim3 grid(svx_cdiv(cols, SPX_W), svx_cdiv(rows - 4, SPX2_ROWS), n_frames);
+    SVX_HIP(ctx, hipFuncSetAttribute((const void *)subpixel_pair_tile_kernel<WORDS, SPX2_CHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    subpixel_pair_tile_kernel<WORDS, SPX2_CHUNKS><<<grid, 256 * SPX2_GROUPS, lds, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_cap, disparity);
+    SVX_LAUNCH_CHECK(ctx, "subpixel_pair_tile_kernel");
+    return SVX_OK;
+}
+
 static int launch_subpixel(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp, float *disparity) {
+    // SVX_OPT_SUBPIXEL_TILES: 2 (default) = both neighbourhoods in LDS where the range of disparities lets two blocks share a CU (wider
+    // ranges measured no faster that way, one block a CU or smaller blocks), else the left one; 1 = the left one; 0 = none.
+    if (rows >= 5 && svx_opt(ctx, SVX_OPT_SUBPIXEL_TILES) == 2 && max_disp - 2 <= SPX2_DCAP)
+        return words == 1 ? launch_subpixel_pair_tiles<1>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity)
+                          : launch_subpixel_pair_tiles<2>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity);
     if (rows >= 5 && svx_opt(ctx, SVX_OPT_SUBPIXEL_TILES) != 0) {
         dim3 grid(svx_cdiv(cols, SPX_W), svx_cdiv(rows - 4, SPX_ROWS), n_frames);
         if (words == 1) subpixel_tile_kernel<1><<<grid, 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity);

@@ -379,11 +379,12 @@ def test_matrix_search_random_sizes(ctx, seed):
 SUBPIXEL_TOL = 1e-3   # px, the tolerance required of sub-pixel disparities; the results are in fact identical
 
 
-@pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (30, 150, 128), (9, 21, 5), (5, 20, 8), (64, 300, 200), (4, 30, 4)])
+@pytest.mark.parametrize("rows,cols,max_disp", [(24, 64, 16), (30, 150, 128), (9, 21, 5), (5, 20, 8), (64, 300, 200), (4, 30, 4), (21, 1300, 1000), (13, 700, 340)])
 @pytest.mark.parametrize("words", [1, 2])
-@pytest.mark.parametrize("tiles", [1, 0])
+@pytest.mark.parametrize("tiles", [2, 1, 0])
 def test_subpixel_refine_matches_oracle(ctx, rows, cols, max_disp, words, tiles):
-    """Both forms of the step: the left descriptors of a block staged in LDS (the default) and every descriptor from memory."""
+    """The three forms of the step: both neighbourhoods of a block staged in LDS (the default up to 252 disparities), the left one
+    alone, and every descriptor from memory."""
     import stereovision_amd as S
     rng = np.random.default_rng(rows * 7 + cols + words)
     shape = (2, rows, cols) + ((2,) if words == 2 else ())
@@ -400,7 +401,7 @@ def test_subpixel_refine_matches_oracle(ctx, rows, cols, max_disp, words, tiles)
     try:
         got = ctx.subpixel_refine(dev_u32(cl), dev_u32(cr), max_disp, dev(disp), words=words).cpu().numpy()
     finally:
-        ctx.set_option(S.OPT_SUBPIXEL_TILES, 1)
+        ctx.set_option(S.OPT_SUBPIXEL_TILES, 2)
     changed = 0
     for f in range(2):
         want = O.subpixel_refine(cl[f], cr[f], max_disp, disp[f])
