@@ -109,10 +109,20 @@ int svx_static_scratch_locate(svx_ctx *ctx);   // svx_dense.hip: finds this devi
 // Matrix-core form of the dense search on two-word descriptors (svx_dense_mx.hip).
 bool svx_mx_sweep_eligible(int rows, int cols, int max_disp);
 size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames, int words, int max_disp);
+// keep_keys: the left map is left as the winners' keys (below) instead of disparities, for a kernel that wants the winners'
+// costs as well; svx_launch_mx_right's check then reads keys and marks a rejected pixel with SVX_MX_NO_KEY.
 int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp,
-                        float *disparity, int write_border, float *partial);
+                        float *disparity, int write_border, float *partial, bool keep_keys = false);
 int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int words, int max_disp,
-                        float *disp_left, float *disp_right, float lr_threshold);
+                        float *disp_left, float *disp_right, float lr_threshold, bool keys = false);
+// A winner's key on two-word descriptors: 1600 - 2 * (cost of the 5x5 window) + (1023 - d) / 1024, exact in a float; a pixel
+// without an admissible pair holds a key below -2048 (disparity 0), and nothing reaches SVX_MX_NO_KEY.
+constexpr float SVX_MX_NO_KEY = -4194304.0f;
+__device__ __forceinline__ float svx_mx_key_disparity(float z) {
+    const float frac = z - __builtin_floorf(z);
+    return z < -2048.0f ? 0.0f : 1023.0f - frac * 1024.0f;
+}
+__device__ __forceinline__ int svx_mx_key_cost(float z) { return (1600 - (int)__builtin_floorf(z)) >> 1; }
 
 // ---- device helpers -------------------------------------------------------
 

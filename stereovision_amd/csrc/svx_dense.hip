@@ -1111,7 +1111,9 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const uint32_t *__restric
 // block instead of 25 times per pixel, which takes 200 of the 480 bytes per pixel off the vector cache; the right
 // descriptors depend on each pixel's own disparity and are gathered from memory as before.  Same arithmetic, same results.
 constexpr int SPX_ROWS = 4, SPX_W = 256, SPX_PITCH = SPX_W + 4;
-template <int WORDS>
+// KEYS (two-word descriptors): the map holds the keys of the matrix-core search's winners instead of disparities (svx_common.hpp),
+// SVX_MX_NO_KEY where the check rejected the pixel: every pixel is decoded and written, and the winner's own cost comes from its key.
+template <int WORDS, bool KEYS = false>
 __global__ __launch_bounds__(256) void subpixel_tile_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                             int rows, int cols, int max_disp, float *__restrict__ disp_all) {
     typedef typename std::conditional<WORDS == 2, uint2, uint32_t>::type desc_t;
@@ -1133,11 +1135,20 @@ __global__ __launch_bounds__(256) void subpixel_tile_kernel(const uint32_t *__re
     for (int j = 0; j < SPX_ROWS; ++j) {
         const int y = y0 + j;
         if (y >= rows - 2) break;
-        const float f = disp[(long)y * cols + x];
-        if (!(f >= 1.0f) || !(f < (float)max_disp)) continue;                     // also NaN and values no int can hold
-        const int d = (int)f;
-        if ((float)d != f || d + 1 > max_disp - 1 || x - (d + 1) < 5) continue;
+        float f = disp[(long)y * cols + x];
         int c0 = 0, c1 = 0, c2 = 0;
+        if constexpr (KEYS) {
+            if (f <= SVX_MX_NO_KEY) { disp[(long)y * cols + x] = -1.0f; continue; }
+            c1 = svx_mx_key_cost(f);
+            f = svx_mx_key_disparity(f);
+        }
+        bool refine = f >= 1.0f && f < (float)max_disp;                          // (false for NaN and values no int can hold)
+        const int d = refine ? (int)f : 0;
+        refine = refine && (float)d == f && d + 1 <= max_disp - 1 && x - (d + 1) >= 5;
+        if (!refine) {
+            if (KEYS) disp[(long)y * cols + x] = f;
+            continue;
+        }
 #pragma unroll
         for (int m = -2; m <= 2; ++m) {
             const desc_t *lrow = tile + (j + 2 + m) * SPX_PITCH + threadIdx.x + 2;
@@ -1150,13 +1161,14 @@ __global__ __launch_bounds__(256) void subpixel_tile_kernel(const uint32_t *__re
                     uint32_t l;
                     if constexpr (WORDS == 2) l = w ? lv.y : lv.x; else l = lv;
                     c0 += popc32(l ^ rrow[(k + 1) * WORDS + w]);      // disparity d-1: right column x-d+1
-                    c1 += popc32(l ^ rrow[k * WORDS + w]);
+                    if (!KEYS) c1 += popc32(l ^ rrow[k * WORDS + w]);
                     c2 += popc32(l ^ rrow[(k - 1) * WORDS + w]);      // disparity d+1
                 }
             }
         }
         const int den = c0 - 2 * c1 + c2;
         if (den > 0) disp[(long)y * cols + x] = (float)d + __fdiv_rn((float)(c0 - c2), (float)(2 * den));
+        else if (KEYS) disp[(long)y * cols + x] = f;
     }
 }
 
@@ -1176,7 +1188,7 @@ __device__ __forceinline__ int popc_acc(uint32_t v, int acc) {
 // exceeds d_cap gathers from memory as before.  RCH = 256-column chunks of the right tile.  Two blocks a CU need 64 registers a
 // thread at most and 80 KiB of LDS a block: two chunks, disparities up to 250.  Same arithmetic, same results.
 constexpr int SPX2_ROWS = 8, SPX2_GROUPS = 4, SPX2_CHUNKS = 2, SPX2_DCAP = 256 * SPX2_CHUNKS - (SPX_W + 6);
-template <int WORDS, int RCH>
+template <int WORDS, int RCH, bool KEYS = false>
 __global__ __launch_bounds__(256 * SPX2_GROUPS, 8) void subpixel_pair_tile_kernel(const uint32_t *__restrict__ cl_all, const uint32_t *__restrict__ cr_all,
                                                                                 int rows, int cols, int max_disp, int d_cap, float *__restrict__ disp_all) {
     typedef typename std::conditional<WORDS == 2, uint2, uint32_t>::type desc_t;
@@ -1222,11 +1234,20 @@ __global__ __launch_bounds__(256 * SPX2_GROUPS, 8) void subpixel_pair_tile_kerne
     for (int j = grp; j < SPX2_ROWS; j += SPX2_GROUPS) {
         const int y = y0 + j;
         if (y >= rows - 2) break;
-        const float f = disp[(long)y * cols + x];
-        if (!(f >= 1.0f) || !(f < (float)max_disp)) continue;                     // also NaN and values no int can hold
-        const int d = (int)f;
-        if ((float)d != f || d + 1 > max_disp - 1 || x - (d + 1) < 5) continue;
+        float f = disp[(long)y * cols + x];
         int c0 = 0, c1 = 0, c2 = 0;
+        if constexpr (KEYS) {                                                     // (see subpixel_tile_kernel)
+            if (f <= SVX_MX_NO_KEY) { disp[(long)y * cols + x] = -1.0f; continue; }
+            c1 = svx_mx_key_cost(f);
+            f = svx_mx_key_disparity(f);
+        }
+        bool refine = f >= 1.0f && f < (float)max_disp;                          // (false for NaN and values no int can hold)
+        const int d = refine ? (int)f : 0;
+        refine = refine && (float)d == f && d + 1 <= max_disp - 1 && x - (d + 1) >= 5;
+        if (!refine) {
+            if (KEYS) disp[(long)y * cols + x] = f;
+            continue;
+        }
         if (d <= d_cap) {
             const desc_t *lbase = ltile + j * SPX_PITCH + col;                    // window column -2 of window row -2
             const desc_t *rbase = rtile + j * r_pitch + (x - d - 3 - rx0);        // right column x - d - 3 of window row -2
@@ -1240,7 +1261,7 @@ __global__ __launch_bounds__(256 * SPX2_GROUPS, 8) void subpixel_pair_tile_kerne
                     const desc_t lw = lbase[m * SPX_PITCH + k];
                     if constexpr (WORDS == 2) {
                         c0 = popc_acc(lw.y ^ rw[k + 2].y, popc_acc(lw.x ^ rw[k + 2].x, c0));      // disparity d-1: right column x-d+1
-                        c1 = popc_acc(lw.y ^ rw[k + 1].y, popc_acc(lw.x ^ rw[k + 1].x, c1));
+                        if (!KEYS) c1 = popc_acc(lw.y ^ rw[k + 1].y, popc_acc(lw.x ^ rw[k + 1].x, c1));
                         c2 = popc_acc(lw.y ^ rw[k].y, popc_acc(lw.x ^ rw[k].x, c2));              // disparity d+1
                     } else {
                         c0 = popc_acc(lw ^ rw[k + 2], c0);
@@ -1263,7 +1284,7 @@ __global__ __launch_bounds__(256 * SPX2_GROUPS, 8) void subpixel_pair_tile_kerne
                         uint32_t l;
                         if constexpr (WORDS == 2) l = w ? lw.y : lw.x; else l = lw;
                         c0 += popc32(l ^ rrow[(k + 1) * WORDS + w]);
-                        c1 += popc32(l ^ rrow[k * WORDS + w]);
+                        if (!KEYS) c1 += popc32(l ^ rrow[k * WORDS + w]);
                         c2 += popc32(l ^ rrow[(k - 1) * WORDS + w]);
                     }
                 }
@@ -1271,21 +1292,32 @@ __global__ __launch_bounds__(256 * SPX2_GROUPS, 8) void subpixel_pair_tile_kerne
         }
         const int den = c0 - 2 * c1 + c2;
         if (den > 0) disp[(long)y * cols + x] = (float)d + __fdiv_rn((float)(c0 - c2), (float)(2 * den));
+        else if (KEYS) disp[(long)y * cols + x] = f;
     }
 }
 
-template <int WORDS>
+template <int WORDS, bool KEYS = false>
 static int launch_subpixel_pair_tiles(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int max_disp, float *disparity) {
     const int d_cap = max_disp - 2 < 0 ? 0 : max_disp - 2 < SPX2_DCAP ? max_disp - 2 : SPX2_DCAP;
     const size_t lds = (size_t)(SPX2_ROWS + 4) * 4 * WORDS * (size_t)(SPX_PITCH + SPX_W + 6 + d_cap);
     const dim3 grid(svx_cdiv(cols, SPX_W), svx_cdiv(rows - 4, SPX2_ROWS), n_frames);
-    SVX_HIP(ctx, hipFuncSetAttribute((const void *)subpixel_pair_tile_kernel<WORDS, SPX2_CHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    subpixel_pair_tile_kernel<WORDS, SPX2_CHUNKS><<<grid, 256 * SPX2_GROUPS, lds, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_cap, disparity);
+    SVX_HIP(ctx, hipFuncSetAttribute((const void *)subpixel_pair_tile_kernel<WORDS, SPX2_CHUNKS, KEYS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    subpixel_pair_tile_kernel<WORDS, SPX2_CHUNKS, KEYS><<<grid, 256 * SPX2_GROUPS, lds, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_cap, disparity);
     SVX_LAUNCH_CHECK(ctx, "subpixel_pair_tile_kernel");
     return SVX_OK;
 }
 
-static int launch_subpixel(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp, float *disparity) {
+// keys: the map holds the matrix-core search's keys (two-word descriptors, rows >= 5, SVX_OPT_SUBPIXEL_TILES not 0: subpixel_from_keys).
+static bool subpixel_from_keys(const svx_ctx *ctx, int rows) { return rows >= 5 && svx_opt(ctx, SVX_OPT_SUBPIXEL_TILES) != 0; }
+static int launch_subpixel(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp, float *disparity,
+                           bool keys = false) {
+    if (keys) {
+        if (max_disp - 2 <= SPX2_DCAP && svx_opt(ctx, SVX_OPT_SUBPIXEL_TILES) == 2)
+            return launch_subpixel_pair_tiles<2, true>(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity);
+        subpixel_tile_kernel<2, true><<<dim3(svx_cdiv(cols, SPX_W), svx_cdiv(rows - 4, SPX_ROWS), n_frames), 256, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, disparity);
+        SVX_LAUNCH_CHECK(ctx, "subpixel_tile_kernel");
+        return SVX_OK;
+    }
     // SVX_OPT_SUBPIXEL_TILES: 2 (default) = both neighbourhoods in LDS where the range of disparities lets two blocks share a CU (wider
     // ranges measured no faster that way, one block a CU or smaller blocks), else the left one; 1 = the left one; 0 = none.
     if (rows >= 5 && svx_opt(ctx, SVX_OPT_SUBPIXEL_TILES) == 2 && max_disp - 2 <= SPX2_DCAP)
@@ -1356,7 +1388,8 @@ static int both_views_group_frames(const svx_ctx *ctx, int rows, int cols, int n
 // What follows the sweep of a group of frames: the right view's disparity map, or the check of the left map against the
 // partial minima (disp_right == nullptr).
 static int launch_both_views(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp,
-                             float *disp_left, float *disp_right, float lr_threshold, int group, uint32_t *partial, bool sweep_only = false) {
+                             float *disp_left, float *disp_right, float lr_threshold, int group, uint32_t *partial, bool sweep_only = false,
+                             bool keys = false) {
     const size_t n = (size_t)rows * cols;
     const int n_xblocks = (cols - 4 + SW_T - 1) / SW_T;
     // Two-word descriptors at up to 256 disparities: the cost values are formed on the matrix cores (at 128: 1.37 ms against
@@ -1368,10 +1401,10 @@ static int launch_both_views(svx_ctx *ctx, const uint32_t *cl, const uint32_t *c
         const uint32_t *gl = cl + (size_t)f0 * n * words, *gr = cr + (size_t)f0 * n * words;
         float *dl = disp_left + (size_t)f0 * n;
         if (mx) {
-            int rc = svx_launch_mx_sweep(ctx, gl, gr, rows, cols, nf, words, max_disp, dl, 1, (float *)partial);
+            int rc = svx_launch_mx_sweep(ctx, gl, gr, rows, cols, nf, words, max_disp, dl, 1, (float *)partial, keys);
             if (rc) return rc;
             if (sweep_only) continue;
-            rc = svx_launch_mx_right(ctx, (const float *)partial, rows, cols, nf, words, max_disp, dl, disp_right ? disp_right + (size_t)f0 * n : nullptr, lr_threshold);
+            rc = svx_launch_mx_right(ctx, (const float *)partial, rows, cols, nf, words, max_disp, dl, disp_right ? disp_right + (size_t)f0 * n : nullptr, lr_threshold, keys);
             if (rc) return rc;
             continue;
         }
@@ -1453,6 +1486,9 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     // the partial minima of the one-sweep path take 80 words per (row, x-block, 64-disparity chunk) and frame
     const int group = lr && !two_sweeps ? both_views_group_frames(ctx, rows, cols, n_frames, 2, max_disp) : 0;
     const bool both = group > 0;
+    // with the sub-pixel step behind a matrix-core search and its check, the map carries the winners' keys until that step decodes them:
+    // it takes each winner's own cost from its key instead of counting it again
+    const bool keys = subpixel && both && both_views_on_matrix_cores(ctx, rows, cols, 2, max_disp) && subpixel_from_keys(ctx, rows);
     const size_t part_words = both ? both_views_partial_words(ctx, rows, cols, group, 2, max_disp) : 0;
     void *ws;
     rc = svx_ws_reserve(ctx, (4 * n + part_words) * sizeof(uint32_t) + (lr && !both ? n * sizeof(float) : 0), &ws);
@@ -1463,7 +1499,7 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     if (rc) return rc;
     if (both) {
         // one sweep; the check reads the right view's partial minima directly (no right disparity map is formed)
-        rc = launch_both_views(ctx, cl, cr, rows, cols, n_frames, 2, max_disp, disparity, nullptr, lr_threshold, group, partial);
+        rc = launch_both_views(ctx, cl, cr, rows, cols, n_frames, 2, max_disp, disparity, nullptr, lr_threshold, group, partial, false, keys);
         if (rc) return rc;
     } else {
         rc = launch_dense(ctx, cl, cr, rows, cols, n_frames, max_disp, disparity, 1, 2, 0);
@@ -1477,7 +1513,7 @@ static int dense_census9x7_impl(svx_ctx *ctx, const uint8_t *left, const uint8_t
     }
     if (subpixel) {
         SVX_REQUIRE(ctx, rows <= 65535, SVX_ERR_UNSUPPORTED, "svx_dense_census9x7_subpixel_u8: too many rows per call");
-        rc = launch_subpixel(ctx, cl, cr, rows, cols, n_frames, 2, max_disp, disparity);
+        rc = launch_subpixel(ctx, cl, cr, rows, cols, n_frames, 2, max_disp, disparity, keys);
     }
     return rc;
 }

@@ -41,7 +41,7 @@ constexpr int MX_M = 32;                 // left columns per wavefront
 #endif
 constexpr int MX_NBUF = 3;               // staged rows in flight: the one being read, the one being written, and one in between (see mx_strip)
 constexpr int MX_KROWS = 3;              // right view: key rows in LDS (the one being written out, the one being filled, and the next one the wavefronts ahead fill)
-constexpr float MX_NO_KEY = -4194304.0f; // below every key, admissible or not
+constexpr float MX_NO_KEY = SVX_MX_NO_KEY; // below every key, admissible or not
 constexpr int mx_pass_step(int tiles) { return 32 * tiles; }   // a range beyond one pass: pass p takes the right columns 32 T p further left (all columns of its T tiles, see mx_plan)
 
 template <int T, int WORDS = 2>
@@ -249,10 +249,7 @@ __device__ __forceinline__ void mx_keys_flush_write(MxState<T, TG> &st, int whic
 
 // Decodes a winner: key = window score + (1023 - d) / 1024 >= -1600; an inadmissible pair sits near -2^20, and a pair that
 // only the other view admits, unlifted, below -2495 (mx_strip).
-__device__ __forceinline__ float mx_decode(float z) {
-    const float frac = z - __builtin_floorf(z);
-    return z < -2048.0f ? 0.0f : 1023.0f - frac * 1024.0f;
-}
+__device__ __forceinline__ float mx_decode(float z) { return svx_mx_key_disparity(z); }
 
 // pass_flags: what a search over part of the disparity range does with the left map.  Bit 0: an earlier pass over smaller
 // disparities left its winner's key in the map, which competes (keys carry their disparity: the larger key is the better
@@ -888,7 +885,8 @@ __global__ __launch_bounds__(256) void mx_right_view_merge_kernel(const float *_
 
 // Left-right check straight from the partial keys (the rule of svx_lr_check with the right disparity merged on demand).
 // One block per row and frame; a thread checks the pixels tid, tid + 256, ... four at a time (their loads are in flight together).
-template <int T>
+// KEYS: the left map holds the winners' keys (svx_launch_mx_sweep, keep_keys); a rejected pixel gets SVX_MX_NO_KEY.
+template <int T, bool KEYS = false>
 __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl_all, const float *__restrict__ partial, long pass_stride, int n_pass,
                                                           int rows, int cols, int n_groups, float threshold, float invalid) {
     const int y = blockIdx.x + 2;
@@ -897,7 +895,10 @@ __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl
     for (int x0 = 2 + threadIdx.x; x0 < cols - 2; x0 += 4 * 256) {
         float d1[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d1[k] = x0 + 256 * k < cols - 2 ? dl[x0 + 256 * k] : 0.0f;
+        for (int k = 0; k < 4; ++k) {
+            d1[k] = x0 + 256 * k < cols - 2 ? dl[x0 + 256 * k] : 0.0f;
+            if (KEYS) d1[k] = mx_decode(d1[k]);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int x = x0 + 256 * k;
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(256) void mx_lr_check_kernel(float *__restrict__ dl
             const int xr = bad ? 0 : x - (int)d1[k];
             bad = bad || xr < 2;
             if (!bad) bad = fabsf(svx_mx_right_disparity<T>(prow, pass_stride, n_pass, xr, cols, n_groups) - d1[k]) > threshold;
-            if (bad) dl[x] = invalid;
+            if (bad) dl[x] = KEYS ? MX_NO_KEY : invalid;
         }
     }
 }
@@ -953,7 +954,7 @@ size_t svx_mx_partial_words(const svx_ctx *ctx, int rows, int cols, int n_frames
 // Left-view search on two-word descriptors; see svx_dense.hip for the meaning of the arguments.
 // partial != nullptr: also the right view's partial keys (svx_mx_partial_words floats).
 int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, int rows, int cols, int n_frames, int words, int max_disp,
-                        float *disparity, int write_border, float *partial) {
+                        float *disparity, int write_border, float *partial, bool keep_keys) {
     const MxPlan plan = mx_plan(ctx, max_disp, words);
     const int T = plan.tiles;
     // Strips: every strip re-reads 4 halo rows and starts with 5 rows that fill the window, but the grid should fill the
@@ -979,7 +980,7 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
     const int nb = mx_xblocks(cols);
     const size_t pass_words = (size_t)n_frames * rows * n_groups * mx_keys_per_group(T);
     for (int p = 0; p < plan.passes; ++p) {
-        const int d_base = p * mx_pass_step(T), flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes ? 2 : 0);
+        const int d_base = p * mx_pass_step(T), flags = (p > 0 ? 1 : 0) | (p + 1 < plan.passes || keep_keys ? 2 : 0);
         const int wb = p + 1 == plan.passes ? write_border : 0;
         float *part = partial ? partial + p * pass_words : nullptr;
 #define MX_LAUNCH(TT, WW, BB, PART) dense_wta_mx_kernel<TT, WW, BB><<<grid, block, 0, ctx->stream>>>(cl, cr, rows, cols, max_disp, d_base, flags, strip_rows, nb, disparity, wb, PART)
@@ -1003,7 +1004,7 @@ int svx_launch_mx_sweep(svx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, in
 // After svx_launch_mx_sweep with partial keys: the right disparity map (disp_right != nullptr) or the left-right
 // check of disp_left in place.
 int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, int n_frames, int words, int max_disp,
-                        float *disp_left, float *disp_right, float lr_threshold) {
+                        float *disp_left, float *disp_right, float lr_threshold, bool keys) {
     const dim3 grid(svx_cdiv(cols, 256), rows, n_frames), check_grid(rows - 4, n_frames);
     const int nb = mx_groups(cols);
     const MxPlan plan = mx_plan(ctx, max_disp, words);
@@ -1011,12 +1012,15 @@ int svx_launch_mx_right(svx_ctx *ctx, const float *partial, int rows, int cols, 
     const int np = plan.passes;
     if (plan.tiles == 9) {
         if (disp_right) mx_right_view_merge_kernel<9><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
+        else if (keys) mx_lr_check_kernel<9, true><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
         else mx_lr_check_kernel<9><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
     } else if (plan.tiles == 3) {
         if (disp_right) mx_right_view_merge_kernel<3><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
+        else if (keys) mx_lr_check_kernel<3, true><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
         else mx_lr_check_kernel<3><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
     } else {
         if (disp_right) mx_right_view_merge_kernel<5><<<grid, 256, 0, ctx->stream>>>(partial, ps, np, rows, cols, nb, disp_right);
+        else if (keys) mx_lr_check_kernel<5, true><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
         else mx_lr_check_kernel<5><<<check_grid, 256, 0, ctx->stream>>>(disp_left, partial, ps, np, rows, cols, nb, lr_threshold, -1.0f);
     }
     SVX_LAUNCH_CHECK(ctx, "mx right view kernel");
