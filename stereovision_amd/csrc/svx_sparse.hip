@@ -234,27 +234,32 @@ __global__ void sparse_bucket_index_kernel(const int32_t *__restrict__ kr, int n
     bucket_first[e] = lo;
 }
 
+// G lanes serve one left feature: a run of candidates holds a handful of features (about four a row at 70 disparities on a KITTI
+// frame), so a whole wavefront per feature leaves most lanes idle; with 16 lanes a wavefront takes four features at once (their
+// reference windows then sit in vector registers instead of scalar ones).
+template <int G>
 __global__ __launch_bounds__(256) void sparse_calc_costs_indexed_kernel(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr, int rows, int cols,
                                                                         const SparseLeft *__restrict__ L, int nl, const SparseRight *__restrict__ R,
                                                                         const int *__restrict__ bucket_first, int nb, int tol_rows,
                                                                         int max_disparity, float y_tol, int *__restrict__ m_first, int *__restrict__ m_cost) {
-    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (l >= nl) return;
+    const int l = blockIdx.x * (256 / G) + (threadIdx.x / G);
+    const int lane = threadIdx.x & (G - 1);
+    if (l >= nl) return;                                   // (a whole group of lanes: the exchanges below stay inside a group)
     const SparseLeft f = L[l];
     if (f.state != 0) {
         if (lane == 0) { m_first[l] = f.state == 1 ? 0 : -1; m_cost[l] = 0; }
         return;
     }
     const long n = (long)rows * cols;
-    const Window6 ref = window6_load(cl, n, cols, __builtin_amdgcn_readfirstlane(f.xi), __builtin_amdgcn_readfirstlane(f.yi));
+    const Window6 ref = G == 64 ? window6_load(cl, n, cols, __builtin_amdgcn_readfirstlane(f.xi), __builtin_amdgcn_readfirstlane(f.yi))
+                                : window6_load(cl, n, cols, f.xi, f.yi);
     const int x_lo = max(f.xi - max_disparity, 2), x_hi = min(f.xi, cols - 3);
     unsigned long long best = ~0ull;
     if (x_lo <= x_hi) {
         const int b0 = x_lo >> SP_BUCKET_SHIFT, b1 = x_hi >> SP_BUCKET_SHIFT;
         for (int y = max(f.yi - tol_rows, 0); y <= min(f.yi + tol_rows, rows - 1); ++y) {
             const int s = max(bucket_first[y * (nb + 1) + b0], f.r_start), e = min(bucket_first[y * (nb + 1) + b1 + 1], f.r_end);
-            for (int r = s + lane; r < e; r += 64) {
+            for (int r = s + lane; r < e; r += G) {
                 const SparseRight g = R[r];
                 const bool ok = g.x <= f.x && g.x >= f.x - (float)max_disparity && fabsf(f.y - g.y) <= y_tol &&
                                 g.x >= 2.0f && g.x < (float)(cols - 2);
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) void sparse_calc_costs_indexed_kernel(const ui
         }
     }
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
+    for (int s = G / 2; s >= 1; s >>= 1) {
         const unsigned long long o = __shfl_xor(best, s, 64);
         best = o < best ? o : best;
     }
@@ -303,8 +308,8 @@ int svx_sparse_match_lists(svx_ctx *ctx, const uint32_t *census_left, const uint
         // (the index's first column is the row-offset table the records are built from)
         sparse_prepare_kernel<<<prep_grid, 256, 0, ctx->stream>>>(left_xy, n_left, right_xy, n_right, rows, y_tolerance, bucket_first, nb + 1, dl, dr);
         SVX_LAUNCH_CHECK(ctx, "sparse_prepare_kernel");
-        sparse_calc_costs_indexed_kernel<<<grid, 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, dl, n_left, dr, bucket_first, nb,
-                                                                       (int)y_tolerance, max_disparity, y_tolerance, first_dev, cost_dev);
+        sparse_calc_costs_indexed_kernel<16><<<svx_cdiv(n_left, 16), 256, 0, ctx->stream>>>(census_left, census_right, rows, cols, dl, n_left, dr, bucket_first, nb,
+                                                                                           (int)y_tolerance, max_disparity, y_tolerance, first_dev, cost_dev);
         SVX_LAUNCH_CHECK(ctx, "sparse_calc_costs_indexed_kernel");
     } else {
         sparse_prepare_kernel<<<prep_grid, 256, 0, ctx->stream>>>(left_xy, n_left, right_xy, n_right, rows, y_tolerance, nullptr, 0, dl, dr);
